@@ -1,0 +1,445 @@
+// api.hip -- the C-ABI of include/bwts.h: context, arenas, staging, timing, test hooks.
+#include "internal.h"
+
+#include <new>
+#include <stdio.h>
+#include <time.h>
+#include <stdlib.h>
+#include <string.h>
+
+// ------------------------------------------------------------------------------------
+// arenas
+// ------------------------------------------------------------------------------------
+int arena_reserve(bwts_ctx *ctx, size_t bytes)
+{
+    bytes = align_up(bytes, 1 << 20);
+    if (bytes > ctx->arena_cap) {
+        if (ctx->arena) { HIPC(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+        ctx->arena = (char *)p;
+        ctx->arena_cap = bytes;
+    }
+    ctx->arena_off = 0;
+    return BWTS_OK;
+}
+
+void arena_reset(bwts_ctx *ctx) { ctx->arena_off = 0; }
+
+void *arena_alloc(bwts_ctx *ctx, size_t bytes)
+{
+    bytes = align_up(bytes ? bytes : 1, 256);
+    if (ctx->arena_off + bytes > ctx->arena_cap) return nullptr;
+    void *p = ctx->arena + ctx->arena_off;
+    ctx->arena_off += bytes;
+    return p;
+}
+
+int aux_reserve(bwts_ctx *ctx, size_t bytes, char **base)
+{
+    bytes = align_up(bytes, 1 << 20);
+    if (bytes > ctx->aux_cap) {
+        // contents of a previous, smaller aux block are never live across this call
+        if (ctx->aux) { HIPC(hipStreamSynchronize(ctx->stream)); HIPC(hipFree(ctx->aux)); ctx->aux = nullptr; ctx->aux_cap = 0; }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+        ctx->aux = (char *)p;
+        ctx->aux_cap = bytes;
+    }
+    *base = ctx->aux;
+    return BWTS_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// timing spans
+// ------------------------------------------------------------------------------------
+static hipEvent_t take_event(bwts_ctx *ctx)
+{
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->ev_pool.push_back(e);
+    }
+    return ctx->ev_pool[ctx->ev_used++];
+}
+
+void spans_reset(bwts_ctx *ctx)
+{
+    ctx->ev_used = 0;
+    ctx->spans.clear();
+    memset(&ctx->tm, 0, sizeof(ctx->tm));
+}
+
+void span_begin(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes)
+{
+    ctx->tm.k[cls].launches++;
+    ctx->tm.k[cls].elems += elems;
+    ctx->tm.k[cls].alg_bytes += alg_bytes;
+    if (!ctx->timing) return;
+    TimedSpan sp;
+    sp.cls = cls;
+    sp.a = take_event(ctx);
+    sp.b = take_event(ctx);
+    if (!sp.a || !sp.b) return;
+    (void)hipEventRecord(sp.a, ctx->stream);
+    ctx->spans.push_back(sp);
+}
+
+void span_end(bwts_ctx *ctx)
+{
+    if (!ctx->timing || ctx->spans.empty()) return;
+    (void)hipEventRecord(ctx->spans.back().b, ctx->stream);
+}
+
+int spans_resolve(bwts_ctx *ctx)
+{
+    HIPC(hipStreamSynchronize(ctx->stream));
+    for (const TimedSpan &sp : ctx->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) ctx->tm.k[sp.cls].ms += ms;
+    }
+    return BWTS_OK;
+}
+
+int read_small(bwts_ctx *ctx, int first, int count)
+{
+    HIPC(hipMemcpyAsync(ctx->h_small + first, ctx->d_small + first, (size_t)count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    return BWTS_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+extern "C" int bwts_ctx_create(bwts_ctx **out, int device_id)
+{
+    if (!out) return BWTS_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return BWTS_E_NODEVICE; }
+    if (device_id < 0 || device_id >= count) return BWTS_E_NODEVICE;
+    bwts_ctx *ctx = new (std::nothrow) bwts_ctx();
+    if (!ctx) return BWTS_E_NOMEM;
+    ctx->device = device_id;
+    ctx->timing = true;
+    if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return BWTS_E_NODEVICE; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BWTS_E_HIP; }
+    void *p = nullptr;
+    if (hipMalloc(&p, 4096 * sizeof(u64)) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_NOMEM; }
+    ctx->d_small = (u64 *)p;
+    if (hipHostMalloc(&p, 4096 * sizeof(u64), hipHostMallocDefault) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_NOMEM; }
+    ctx->h_small = (u64 *)p;
+    if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_HIP; }
+    *out = ctx;
+    return BWTS_OK;
+}
+
+extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->aux) (void)hipFree(ctx->aux);
+    if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    for (int i = 0; i < 2; i++) if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// ------------------------------------------------------------------------------------
+// transforms
+// ------------------------------------------------------------------------------------
+typedef int (*device_impl_fn)(bwts_ctx *, const u8 *, u64, u8 *);
+
+static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n, void *d_out)
+{
+    if (!ctx || !d_in || !d_out || n == 0) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    const double keep_h2d = ctx->tm.h2d_ms;
+    spans_reset(ctx);
+    ctx->tm.h2d_ms = keep_h2d;
+    ctx->tm.n = n;
+    HIPC(hipEventRecord(ctx->ev_begin, ctx->stream));
+    int rc = fn(ctx, (const u8 *)d_in, n, (u8 *)d_out);
+    if (rc != BWTS_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    HIPC(hipEventRecord(ctx->ev_end, ctx->stream));
+    BWTS_TRY(spans_resolve(ctx));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+    ctx->tm.total_ms = ms;
+    return BWTS_OK;
+}
+
+extern "C" int bwts_forward_device(bwts_ctx *ctx, const void *d_in, uint64_t n, void *d_out)
+{
+    if (ctx) ctx->tm.h2d_ms = 0;
+    return run_device(ctx, forward_device_impl, d_in, n, d_out);
+}
+
+extern "C" int bwts_inverse_device(bwts_ctx *ctx, const void *d_in, uint64_t n, void *d_out)
+{
+    if (ctx) ctx->tm.h2d_ms = 0;
+    return run_device(ctx, inverse_device_impl, d_in, n, d_out);
+}
+
+// Host buffers (typically an mmap of the input file): chunked through two pinned bounce
+// buffers so the page-in of chunk i+1 overlaps the DMA of chunk i.
+#define STAGE_CHUNK ((size_t)64 << 20)
+
+static int ensure_pinned(bwts_ctx *ctx)
+{
+    for (int i = 0; i < 2; i++) {
+        if (!ctx->pinned[i]) {
+            void *p = nullptr;
+            if (hipHostMalloc(&p, STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+            ctx->pinned[i] = (char *)p;
+        }
+    }
+    ctx->pinned_cap = STAGE_CHUNK;
+    return BWTS_OK;
+}
+
+static int staged_h2d(bwts_ctx *ctx, u8 *d_dst, const u8 *h_src, u64 n)
+{
+    BWTS_TRY(ensure_pinned(ctx));
+    hipEvent_t done[2];
+    HIPC(hipEventCreate(&done[0]));
+    HIPC(hipEventCreate(&done[1]));
+    int rc = BWTS_OK;
+    u64 off = 0;
+    for (int i = 0; off < n; i ^= 1) {
+        const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
+        if (off >= 2 * STAGE_CHUNK && hipEventSynchronize(done[i]) != hipSuccess) { rc = BWTS_E_HIP; break; }
+        memcpy(ctx->pinned[i], h_src + off, len);
+        if (hipMemcpyAsync(d_dst + off, ctx->pinned[i], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipEventRecord(done[i], ctx->stream) != hipSuccess) { rc = BWTS_E_HIP; break; }
+        off += len;
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BWTS_E_HIP;
+    (void)hipEventDestroy(done[0]);
+    (void)hipEventDestroy(done[1]);
+    return rc;
+}
+
+static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n)
+{
+    BWTS_TRY(ensure_pinned(ctx));
+    u64 off = 0;
+    // copy chunk i to pinned[i&1], then memcpy out while the next chunk is in flight
+    size_t prev_len = 0; u64 prev_off = 0; int prev_buf = -1;
+    for (int i = 0; off < n || prev_buf >= 0; i ^= 1) {
+        size_t len = 0;
+        if (off < n) {
+            len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
+            HIPC(hipMemcpyAsync(ctx->pinned[i], d_src + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (prev_buf >= 0) memcpy(h_dst + prev_off, ctx->pinned[prev_buf], prev_len);
+        HIPC(hipStreamSynchronize(ctx->stream));
+        if (off < n) { prev_buf = i; prev_off = off; prev_len = len; off += len; }
+        else prev_buf = -1;
+    }
+    return BWTS_OK;
+}
+
+static double wall_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+
+static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_t n, uint8_t *out)
+{
+    if (!ctx || !in || !out || n == 0) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    void *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_in, n) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+    if (hipMalloc(&d_out, n) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_in); return BWTS_E_NOMEM; }
+    double t0 = wall_ms();
+    int rc = staged_h2d(ctx, (u8 *)d_in, in, n);
+    const double h2d = wall_ms() - t0;
+    if (rc == BWTS_OK) { ctx->tm.h2d_ms = h2d; rc = run_device(ctx, fn, d_in, n, d_out); }
+    if (rc == BWTS_OK) {
+        t0 = wall_ms();
+        rc = staged_d2h(ctx, out, (const u8 *)d_out, n);
+        ctx->tm.d2h_ms = wall_ms() - t0;
+        ctx->tm.h2d_ms = h2d;
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+extern "C" int bwts_forward(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out)
+{
+    return run_host(ctx, forward_device_impl, in, n, out);
+}
+
+extern "C" int bwts_inverse(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out)
+{
+    return run_host(ctx, inverse_device_impl, in, n, out);
+}
+
+// ------------------------------------------------------------------------------------
+// introspection
+// ------------------------------------------------------------------------------------
+extern "C" int bwts_last_timings(bwts_ctx *ctx, bwts_timings *t)
+{
+    if (!ctx || !t) return BWTS_E_ARG;
+    *t = ctx->tm;
+    return BWTS_OK;
+}
+
+extern "C" const char *bwts_kernel_class_name(int k)
+{
+    static const char *names[BWTS_K_COUNT] = {"histogram", "keybuild", "radix_hist", "radix_scan", "radix_scatter", "rerank",
+                                              "lyndon", "emit", "lf_build", "walk", "listrank", "walk_emit", "other"};
+    return (k >= 0 && k < BWTS_K_COUNT) ? names[k] : "?";
+}
+
+extern "C" const char *bwts_strerror(int code)
+{
+    switch (code) {
+    case BWTS_OK: return "ok";
+    case BWTS_E_ARG: return "invalid argument (null pointer or empty input)";
+    case BWTS_E_NODEVICE: return "no usable HIP device";
+    case BWTS_E_NOMEM: return "out of device or pinned host memory";
+    case BWTS_E_HIP: return "HIP runtime error";
+    case BWTS_E_RANGE: return "input length beyond the engine's index range";
+    case BWTS_E_INTERNAL: return "internal invariant violated";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int bwts_last_hip_error(bwts_ctx *ctx) { return ctx ? ctx->last_hip : 0; }
+
+// ------------------------------------------------------------------------------------
+// harness utilities
+// ------------------------------------------------------------------------------------
+extern "C" int bwts_generate_device(bwts_ctx *ctx, int kind, uint64_t seed, uint64_t n, void *d_out)
+{
+    if (!ctx || !d_out) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    return generate_device_impl(ctx, kind, seed, n, (u8 *)d_out);
+}
+
+extern "C" int bwts_device_alloc(bwts_ctx *ctx, uint64_t bytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+    return BWTS_OK;
+}
+
+extern "C" int bwts_device_free(bwts_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipFree(d_ptr));
+    return BWTS_OK;
+}
+
+extern "C" int bwts_copy_to_device(bwts_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!d_dst || !h_src))) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return BWTS_OK;
+}
+
+extern "C" int bwts_copy_to_host(bwts_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!h_dst || !d_src))) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return BWTS_OK;
+}
+
+extern "C" int bwts_device_equal(bwts_ctx *ctx, const void *d_a, const void *d_b, uint64_t bytes, int *equal)
+{
+    if (!ctx || !equal) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    return device_equal_impl(ctx, (const u8 *)d_a, (const u8 *)d_b, bytes, equal);
+}
+
+// ------------------------------------------------------------------------------------
+// unit-test hooks
+// ------------------------------------------------------------------------------------
+extern "C" int bwts_debug_sort_pairs(bwts_ctx *ctx, uint64_t *h_keys, uint32_t *h_vals, uint64_t m, int key_bits)
+{
+    if (!ctx || !h_keys || !h_vals) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    spans_reset(ctx);
+    const size_t need = 2 * align_up(m * 8, 256) + 2 * align_up(m * 4, 256) + radix_tile_hist_bytes(m) + scan_temp_bytes(m) + 4096;
+    BWTS_TRY(arena_reserve(ctx, need));
+    SortPlan plan;
+    plan.keys[0] = arena_array<u64>(ctx, m); plan.keys[1] = arena_array<u64>(ctx, m);
+    plan.vals[0] = arena_array<u32>(ctx, m); plan.vals[1] = arena_array<u32>(ctx, m);
+    plan.tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(m));
+    plan.scan_temp = arena_alloc(ctx, scan_temp_bytes(m));
+    if (!plan.keys[0] || !plan.keys[1] || !plan.vals[0] || !plan.vals[1] || !plan.tile_hist || !plan.scan_temp) return BWTS_E_NOMEM;
+    HIPC(hipMemcpyAsync(plan.keys[0], h_keys, m * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipMemcpyAsync(plan.vals[0], h_vals, m * 4, hipMemcpyHostToDevice, ctx->stream));
+    int res = 0;
+    BWTS_TRY(radix_sort_pairs(ctx, plan, m, key_bits, &res));
+    HIPC(hipMemcpyAsync(h_keys, plan.keys[res], m * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipMemcpyAsync(h_vals, plan.vals[res], m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BWTS_TRY(spans_resolve(ctx));
+    return BWTS_OK;
+}
+
+static int upload_text(bwts_ctx *ctx, const uint8_t *in, uint64_t n, u8 **d_T)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, n) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+    if (hipMemcpy(p, in, n, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); return BWTS_E_HIP; }
+    *d_T = (u8 *)p;
+    return BWTS_OK;
+}
+
+extern "C" int bwts_debug_suffix_array(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint32_t *h_sa)
+{
+    if (!ctx || !in || !h_sa || n == 0) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    spans_reset(ctx);
+    u8 *d_T = nullptr;
+    BWTS_TRY(upload_text(ctx, in, n, &d_T));
+    int rc = arena_reserve(ctx, forward_arena_bytes(n));
+    u32 *sa = nullptr, *rank = nullptr, rounds = 0;
+    if (rc == BWTS_OK) rc = suffix_sort_device(ctx, d_T, n, &sa, &rank, &rounds);
+    if (rc == BWTS_OK && hipMemcpyAsync(h_sa, sa, n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = BWTS_E_HIP;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == BWTS_OK) rc = BWTS_E_HIP;
+    (void)hipFree(d_T);
+    return rc;
+}
+
+extern "C" int bwts_debug_lyndon(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint64_t *h_starts, uint64_t cap, uint64_t *count)
+{
+    if (!ctx || !in || !h_starts || !count || n == 0) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    spans_reset(ctx);
+    u8 *d_T = nullptr;
+    BWTS_TRY(upload_text(ctx, in, n, &d_T));
+    int rc = arena_reserve(ctx, forward_arena_bytes(n));
+    u32 *fstart = nullptr, rounds = 0;
+    u64 k = 0;
+    if (rc == BWTS_OK) rc = lyndon_factors_device(ctx, d_T, n, &fstart, &k, &rounds);
+    if (rc == BWTS_OK) {
+        const u64 take = k < cap ? k : cap;
+        u32 *tmp = (u32 *)malloc((size_t)(take ? take : 1) * 4);
+        if (!tmp) rc = BWTS_E_NOMEM;
+        else {
+            if (hipMemcpy(tmp, fstart, take * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = BWTS_E_HIP;
+            for (u64 i = 0; i < take; i++) h_starts[i] = tmp[i];
+            free(tmp);
+        }
+        *count = k;
+    }
+    (void)hipFree(d_T);
+    return rc;
+}

@@ -1,0 +1,119 @@
+// internal.h -- host-side plumbing shared by the engine's translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+
+#include "../../include/bwts.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t  u8;
+
+struct TimedSpan {
+    int cls;
+    hipEvent_t a, b;
+};
+
+struct bwts_ctx {
+    int device;
+    hipStream_t stream;
+    int last_hip;
+
+    // device arena: one allocation, bump-allocated per call, grown between calls
+    char  *arena;
+    size_t arena_cap, arena_off;
+    char  *aux;
+    size_t aux_cap;
+
+    // small pinned host block for read-backs, and a device mirror
+    u64 *h_small;          // 4096 u64
+    u64 *d_small;          // 4096 u64
+
+    // pinned staging for host-buffer entry points
+    char  *pinned[2];
+    size_t pinned_cap;
+
+    // event pool + spans of the current call
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used;
+    std::vector<TimedSpan> spans;
+    hipEvent_t ev_begin, ev_end;
+    bool timing;
+
+    bwts_timings tm;
+};
+
+#define HIPC(call)                                                        \
+    do {                                                                  \
+        hipError_t e__ = (call);                                          \
+        if (e__ != hipSuccess) { ctx->last_hip = (int)e__; return BWTS_E_HIP; } \
+    } while (0)
+
+#define BWTS_TRY(call)                   \
+    do {                                 \
+        int rc__ = (call);               \
+        if (rc__ != BWTS_OK) return rc__; \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- arena -------------------------------------------------------------------
+int  arena_reserve(bwts_ctx *ctx, size_t bytes);        // (re)allocates when too small; resets
+void arena_reset(bwts_ctx *ctx);
+void *arena_alloc(bwts_ctx *ctx, size_t bytes);         // NULL when exhausted
+template <typename T> static inline T *arena_array(bwts_ctx *ctx, u64 count)
+{
+    return (T *)arena_alloc(ctx, (size_t)count * sizeof(T));
+}
+
+// ---- timing ------------------------------------------------------------------
+void span_begin(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes);
+void span_end(bwts_ctx *ctx);
+void spans_reset(bwts_ctx *ctx);
+int  spans_resolve(bwts_ctx *ctx);
+
+struct SpanGuard {
+    bwts_ctx *c;
+    SpanGuard(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes) : c(ctx) { span_begin(ctx, cls, elems, alg_bytes); }
+    ~SpanGuard() { span_end(c); }
+};
+
+// ---- read-back of a few u64 words (synchronises the stream) --------------------
+int read_small(bwts_ctx *ctx, int first, int count);    // d_small[first..) -> h_small[first..)
+
+// ---- device-wide primitives (scan.hip) ------------------------------------------
+size_t scan_temp_bytes(u64 n);
+int exclusive_sum_u32(bwts_ctx *ctx, u32 *data, u64 n, void *temp);   // in place, wraps mod 2^32
+
+// ---- LSD radix sort of (u64 key, u32 value) pairs (radix.hip) -------------------
+struct SortPlan {
+    u64  *keys[2];
+    u32  *vals[2];
+    u32  *tile_hist;      // 256 * tiles(m)
+    void *scan_temp;
+};
+u64    radix_tiles(u64 m);
+size_t radix_tile_hist_bytes(u64 m);
+// Sorts on key bits [0, key_bits); returns in *result_buf which of keys[]/vals[] holds the output.
+int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, int *result_buf);
+int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp);
+
+// ---- forward / inverse drivers ----------------------------------------------------
+int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out);
+int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out);
+size_t forward_arena_bytes(u64 n);
+size_t inverse_arena_bytes(u64 n);
+
+// non-cyclic suffix sort: leaves the suffix array in *d_sa (arena memory) and ranks in *d_rank
+int suffix_sort_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u32 **d_sa, u32 **d_rank, u32 *rounds);
+int lyndon_factors_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u32 **d_fstart, u64 *k, u32 *rounds);
+int byte_histogram_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u64 *d_hist256);
+int aux_reserve(bwts_ctx *ctx, size_t bytes, char **base);   // second arena, sized on demand
+
+// ---- generators / utilities (gen.hip) ------------------------------------------------
+int generate_device_impl(bwts_ctx *ctx, int kind, u64 seed, u64 n, u8 *d_out);
+int device_equal_impl(bwts_ctx *ctx, const u8 *a, const u8 *b, u64 bytes, int *equal);

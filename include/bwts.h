@@ -1,0 +1,120 @@
+/*
+ * bwts.h -- C-ABI of the MI355X-native bijective-BWT (BWTS) engine (libbwts_hip.so).
+ *
+ * The reference (NealB/Bijective-BWT) has no FFI: its transform core is inline C
+ * on file-scope globals.  These entry points sit exactly on the seams the two
+ * reference programs would bind if their cores were swapped for this engine:
+ *
+ *   bwts_forward()  replaces  divsufsort(T, sa, len) + make_bwts_sa()
+ *                             /root/reference/mk_bwts_sa.c:47-52 (core :74-195)
+ *   bwts_inverse()  replaces  the histogram / scan / LF / cycle-walk block
+ *                             /root/reference/unbwts.c:31-86
+ *
+ * Plain pointers and sizes only.  Every call returns 0 or a negative BWTS_E_*
+ * code and never exits the process (the reference CLIs print and exit(1); the
+ * CLIs in bijective-bwt_amd/cli keep that behaviour on top of these codes).
+ * A context belongs to one GPU and is used by one host thread at a time;
+ * different contexts are independent.
+ *
+ * There is no CPU fallback: without a usable HIP device bwts_ctx_create() fails
+ * with BWTS_E_NODEVICE.
+ */
+#ifndef BWTS_H
+#define BWTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BWTS_OK          0
+#define BWTS_E_ARG      -1   /* NULL pointer, n == 0 (the reference fails on empty input: map_file.c:36-40) */
+#define BWTS_E_NODEVICE -2   /* no HIP device / device id out of range */
+#define BWTS_E_NOMEM    -3   /* device or pinned-host allocation failed */
+#define BWTS_E_HIP      -4   /* a HIP runtime call failed; see bwts_last_hip_error() */
+#define BWTS_E_RANGE    -5   /* n beyond what the engine indexes (n > 2^32 forward, n >= 2^31 inverse) */
+#define BWTS_E_INTERNAL -6   /* engine invariant violated (bug) */
+
+typedef struct bwts_ctx bwts_ctx;
+
+/* Kernel classes timed with HIP events on the engine's stream. */
+enum {
+    BWTS_K_HISTOGRAM = 0,   /* byte histogram (forward alphabet / unbwts.c:34-36)        */
+    BWTS_K_KEYBUILD,        /* round-0 packed-symbol keys / round-h (rank,rank) keys       */
+    BWTS_K_RADIX_HIST,      /* per-tile digit histogram of one LSD pass                   */
+    BWTS_K_RADIX_SCAN,      /* exclusive scan of the tile x digit table                   */
+    BWTS_K_RADIX_SCATTER,   /* ranked, LDS-staged scatter of one LSD pass (dominant)      */
+    BWTS_K_RERANK,          /* group flags + head scan + rank scatter + active compaction */
+    BWTS_K_LYNDON,          /* prefix-min scan over suffix ranks -> factor heads          */
+    BWTS_K_EMIT,            /* bwts[r] = T[cprev(sa[r])] gather (mk_bwts_sa.c:172-188)     */
+    BWTS_K_LF_BUILD,        /* stable LF map (unbwts.c:50-52)                              */
+    BWTS_K_WALK,            /* splitter walk over LF cycles, pass 1 (unbwts.c:66-86)       */
+    BWTS_K_LISTRANK,        /* reduced-list ranking of splitter nodes                     */
+    BWTS_K_WALK_EMIT,       /* splitter walk, pass 2: writes the text                     */
+    BWTS_K_OTHER,
+    BWTS_K_COUNT
+};
+
+typedef struct bwts_kernel_stat {
+    double   ms;         /* summed device time of this class in the last call            */
+    uint64_t launches;   /* number of launches                                           */
+    uint64_t elems;      /* summed elements processed                                    */
+    uint64_t alg_bytes;  /* summed ALGORITHMIC bytes, not fetched   */
+} bwts_kernel_stat;
+
+typedef struct bwts_timings {
+    double   total_ms;            /* device time of the last call, first launch to last   */
+    double   h2d_ms, d2h_ms;      /* staging copies (host-buffer entry points only)       */
+    uint64_t n;                   /* input length of the last call                        */
+    uint64_t factors;             /* forward: Lyndon factors; inverse: LF cycles          */
+    uint32_t rounds;              /* forward: sort rounds of the cyclic sort              */
+    uint32_t lyndon_rounds;       /* forward: sort rounds spent finding the factors       */
+    uint32_t key_symbols;         /* symbols packed into a round-0 key                    */
+    uint32_t key_bits;            /* bits of a round-0 key                                */
+    uint64_t active_after_round0; /* elements still tied after round 0                    */
+    uint64_t unvisited;           /* inverse: elements in cycles without a splitter       */
+    bwts_kernel_stat k[BWTS_K_COUNT];
+} bwts_timings;
+
+int  bwts_ctx_create(bwts_ctx **out, int device_id);
+void bwts_ctx_destroy(bwts_ctx *ctx);
+
+/* Host-buffer entry points: in/out are caller-owned host memory (may be an
+ * mmap of a file, unpinned); staged through pinned buffers with hipMemcpyAsync. */
+int bwts_forward(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out);
+int bwts_inverse(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out);
+
+/* Device-buffer entry points: d_in/d_out are device pointers on the context's
+ * GPU (d_out may not alias d_in).  Synchronous: the call returns after the
+ * result is complete in d_out. */
+int bwts_forward_device(bwts_ctx *ctx, const void *d_in, uint64_t n, void *d_out);
+int bwts_inverse_device(bwts_ctx *ctx, const void *d_in, uint64_t n, void *d_out);
+
+/* Statistics of the last forward/inverse call on this context. */
+int bwts_last_timings(bwts_ctx *ctx, bwts_timings *t);
+const char *bwts_kernel_class_name(int k);
+
+const char *bwts_strerror(int code);
+int bwts_last_hip_error(bwts_ctx *ctx);          /* hipError_t of the last BWTS_E_HIP */
+
+/* Harness utilities (bench / tests): synthetic inputs of SURVEY.md 8(d) written
+ * straight into device memory (kind 0 uniform256, 1 zipf, 2 dna), device
+ * buffers without a tensor library, and a 64-bit FNV-style checksum. */
+int bwts_generate_device(bwts_ctx *ctx, int kind, uint64_t seed, uint64_t n, void *d_out);
+int bwts_device_alloc(bwts_ctx *ctx, uint64_t bytes, void **d_ptr);
+int bwts_device_free(bwts_ctx *ctx, void *d_ptr);
+int bwts_copy_to_device(bwts_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int bwts_copy_to_host(bwts_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int bwts_device_equal(bwts_ctx *ctx, const void *d_a, const void *d_b, uint64_t bytes, int *equal);
+
+/* Unit-test hooks for single kernels (stable LSD radix sort of (u64 key, u32
+ * value) pairs on the low key_bits bits; suffix array via the non-cyclic sort). */
+int bwts_debug_sort_pairs(bwts_ctx *ctx, uint64_t *h_keys, uint32_t *h_vals, uint64_t m, int key_bits);
+int bwts_debug_suffix_array(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint32_t *h_sa);
+int bwts_debug_lyndon(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint64_t *h_starts, uint64_t cap, uint64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
