@@ -45,7 +45,45 @@ def cpu_baseline(kind, sample_log2n):
     }
 
 
-def main():
+class _SleepEngine:
+    """Stand-in used ONLY by --selftest-sleep-ms: runs no transform and touches no GPU."""
+
+    class _T:
+        total_ms = 0.0
+
+        def as_dict(self):
+            return {"kernels": {}, "factors": 0, "rounds": 0, "lyndon_rounds": 0, "key_symbols": 0, "key_bits": 0,
+                    "active_after_round0": 0, "unvisited": 0, "total_ms": 0.0}
+
+    class _B:
+        def free(self):
+            pass
+
+    def __init__(self, rank, ms):
+        self.delay = (rank + 1) * ms / 1e3
+
+    def alloc(self, n):
+        return self._B()
+
+    def generate(self, *a):
+        pass
+
+    def forward_device(self, *a):
+        time.sleep(self.delay)
+
+    inverse_device = forward_device
+
+    def device_equal(self, *a):
+        return True
+
+    def timings(self):
+        return self._T()
+
+    def close(self):
+        pass
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -55,32 +93,42 @@ def main():
     ap.add_argument("--inverse-steps", type=int, default=2)
     ap.add_argument("--cpu-sample-log2n", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--selftest-sleep-ms", type=float, default=0.0,
+                    help="harness self-test (tests/test_dist_cpu.py): no GPU, no transform; every step sleeps "
+                         "(rank+1) x this many ms so the rank/barrier/max-reduce/aggregate logic runs under gloo")
+    args = ap.parse_args(argv)
 
     import torch
-    import __graft_entry__ as ge
-    pkg = ge.load_package()
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    selftest = args.selftest_sleep_ms > 0
+    dev = "cpu" if selftest else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if selftest:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
 
     def barrier():
         if dist is not None:
-            t = torch.zeros(1, device="cuda")
+            t = torch.zeros(1, device=dev)
             dist.all_reduce(t)          # RCCL used as a barrier only
-        torch.cuda.synchronize()
+        if not selftest:
+            torch.cuda.synchronize()
 
     n = 1 << args.log2n
-    ctx = pkg.Context(local_rank)
+    if selftest:
+        ctx = _SleepEngine(rank, args.selftest_sleep_ms)
+    else:
+        import __graft_entry__ as ge
+        ctx = ge.load_package().Context(local_rank)
     d_in = ctx.alloc(n)
     d_out = ctx.alloc(n)
     d_back = ctx.alloc(n)
@@ -121,7 +169,7 @@ def main():
     inv_s = time.perf_counter() - t0
     inv_info = ti.as_dict()
 
-    times = torch.tensor([fwd_s, inv_s, 0.0 if roundtrip else 1.0], dtype=torch.float64, device="cuda")
+    times = torch.tensor([fwd_s, inv_s, 0.0 if roundtrip else 1.0], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     fwd_s, inv_s, bad = [float(v) for v in times.tolist()]
@@ -161,7 +209,9 @@ def main():
             "inverse": {"cycles": inv_info["factors"], "unvisited": inv_info["unvisited"], "device_ms": round(inv_info["total_ms"], 3),
                         "kernels": per_kernel(inv_agg)},
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if selftest:
+            line["data"] = "selftest (no transform executed)"
+        if n_gpus == 1 and not args.no_cpu_baseline and not selftest:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_log2n)
         print(json.dumps(line))
     for b in (d_in, d_out, d_back):

@@ -1,0 +1,42 @@
+"""CPU suite: the N>1 path of bench.py (one process per GPU, barrier, max-over-ranks timing,
+whole-job aggregate, rank 0 prints one JSON line) under gloo with world_size 2.  The path has no
+data-path collective -- replicas only -- so the harness self-test stand-in (sleeps, no transform)
+exercises everything that differs from N=1."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(nproc, extra, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(nproc)] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300, cwd=ROOT)
+
+
+def test_world_size_2_gloo():
+    r = _launch(2, ["--steps", "3", "--warmup", "1", "--log2n", "20", "--selftest-sleep-ms", "20", "--inverse-steps", "1"], 29577)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["higher_is_better"] is True and j["vs_baseline"] is None and j["unit"] == "MB/s"
+    # slowest rank sleeps 2 x 20 ms per step: the MAX over ranks sets the time, the value is the aggregate of both
+    assert 40.0 <= j["ms_per_step"] < 80.0
+    expect = 2 * (1 << 20) / 1e6 / (j["ms_per_step"] / 1e3)
+    assert abs(j["value"] - expect) / expect < 0.01
+    assert j["roundtrip_exact"] is True and "cpu_baseline" not in j
+
+
+def test_single_process_selftest():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--log2n", "16",
+                        "--selftest-sleep-ms", "5", "--inverse-steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    j = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 1 and 5.0 <= j["ms_per_step"] < 30.0

@@ -1,0 +1,228 @@
+"""GPU suite (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden vectors, and -- at BASELINE.json's sizes -- through
+size-independent properties.  Integer/byte work: every comparison is bit-exact."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from test_oracle import ADVERSARIAL, KAT, REF, fib_word
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "bijective-bwt_amd")
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel-level
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,bits", [(1, 8), (2, 1), (63, 8), (64, 16), (65, 64), (4095, 24), (4096, 32), (4097, 64),
+                                    (100003, 40), (1 << 20, 64), (3 << 20, 63)])
+def test_radix_sort_pairs_stable(ctx, m, bits):
+    rng = np.random.default_rng(m * 131 + bits)
+    k = rng.integers(0, 2**63, size=m, dtype=np.uint64)
+    if bits < 64:
+        k &= np.uint64((1 << bits) - 1)
+    if m > 1000:   # heavy duplicates exercise stability and the skewed-digit paths
+        k[: m // 2] = k[0] & np.uint64(0xFF00FF)
+    v = np.arange(m, dtype=np.uint32)
+    ks, vs = ctx.debug_sort_pairs(k, v, bits)
+    order = np.argsort(k, kind="stable")
+    assert np.array_equal(ks, k[order])
+    assert np.array_equal(vs, v[order])
+
+
+def _inputs_small():
+    rng = np.random.default_rng(77)
+    out = [(name, np.frombuffer(bytes(x), dtype=np.uint8)) for name, x in
+           [("adv%d" % i, a) for i, a in enumerate(ADVERSARIAL)]]
+    for sigma in (1, 2, 3, 4, 256):
+        for n in (1, 2, 7, 64, 65, 199, 2049, 4097):
+            out.append(("rand-s%d-n%d" % (sigma, n), rng.integers(0, sigma, size=n, dtype=np.uint8)))
+    for kind in ("uniform256", "zipf", "dna"):
+        for n in (1000, 70001):
+            out.append(("%s-%d" % (kind, n), O.generate(kind, n, 3)))
+    out.append(("fib20", np.frombuffer(fib_word(20), dtype=np.uint8)))
+    out.append(("period-long", np.frombuffer((b"abcab" * 5000) + b"b", dtype=np.uint8)))
+    out.append(("runs", np.frombuffer(b"".join(bytes([c]) * 3000 for c in (5, 4, 9, 4, 5, 1)), dtype=np.uint8)))
+    return out
+
+
+SMALL = _inputs_small()
+
+
+@pytest.mark.parametrize("name,x", SMALL, ids=[s[0] for s in SMALL])
+def test_suffix_array_and_lyndon_vs_oracle(ctx, name, x):
+    assert np.array_equal(ctx.debug_suffix_array(x).astype(np.int64), O.suffix_array(x).astype(np.int64))
+    assert np.array_equal(ctx.debug_lyndon(x).astype(np.int64), O.lyndon_starts(x))
+
+
+# ---------------------------------------------------------------------------------------------
+# transform-level parity
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,x", SMALL, ids=[s[0] for s in SMALL])
+def test_forward_inverse_vs_oracle_small(ctx, name, x):
+    y = ctx.forward(x)
+    assert np.array_equal(y, O.forward(x))
+    if x.size <= 300:
+        assert np.array_equal(y, O.forward_def(x))
+    assert y[0] == x[-1]                                    # mk_bwts_sa.c:188
+    assert np.array_equal(ctx.inverse(y), x)                # unbwts o mk_bwts = id
+    assert np.array_equal(ctx.inverse(x), O.inverse(x))     # any bytes are a valid inverse input
+    assert np.array_equal(ctx.forward(ctx.inverse(x)), x)   # mk_bwts o unbwts = id
+
+
+def test_known_answers_through_cabi(ctx):
+    for text, bwts in KAT["text_to_bwts"]:
+        assert ctx.forward(text.encode()).tobytes() == bwts.encode()
+        assert ctx.inverse(bwts.encode()).tobytes() == text.encode()
+    for text, bwts in KAT["hex_to_bwts"]:
+        assert ctx.forward(bytes.fromhex(text)).tobytes().hex() == bwts
+        assert ctx.inverse(bytes.fromhex(bwts)).tobytes().hex() == text
+    assert hashlib.sha256(ctx.forward(bytes(range(256))).tobytes()).hexdigest().startswith(KAT["bytes_asc_sha256_prefix"])
+    assert hashlib.sha256(ctx.forward(bytes(range(255, -1, -1))).tobytes()).hexdigest().startswith(KAT["bytes_desc_sha256_prefix"])
+
+
+def test_reference_unbwts_vectors_through_cabi(ctx):
+    for rec in REF["small"]:
+        y, x = bytes.fromhex(rec["bwts"]), bytes.fromhex(rec["text"])
+        assert ctx.inverse(y).tobytes() == x
+        assert ctx.forward(x).tobytes() == y
+
+
+@pytest.mark.parametrize("rec", KAT["large"], ids=lambda r: "%s-%d" % (r["kind"], r["n"]))
+def test_large_golden_hashes(ctx, rec):
+    """Hashes produced by the compiled reference, inputs generated on the device."""
+    n = rec["n"]
+    d_in, d_out, d_back = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    try:
+        ctx.generate(rec["kind"], rec["seed"], n, d_in)
+        assert hashlib.sha256(d_in.download().tobytes()).hexdigest() == rec["sha256_in"]   # device generator == spec
+        ctx.forward_device(d_in, n, d_out)
+        assert hashlib.sha256(d_out.download().tobytes()).hexdigest() == rec["sha256_bwts"]
+        ctx.inverse_device(d_out, n, d_back)
+        assert ctx.device_equal(d_in, d_back, n)
+    finally:
+        for b in (d_in, d_out, d_back):
+            b.free()
+
+
+@pytest.mark.parametrize("rec", REF["large"], ids=lambda r: "%s-%d" % (r["kind"], r["n"]))
+def test_large_reference_unbwts_hashes(ctx, rec):
+    y = O.generate(rec["kind"], rec["n"], rec["seed"])
+    x = ctx.inverse(y)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == rec["sha256_text"]
+    assert np.array_equal(ctx.forward(x), y)
+
+
+@pytest.mark.parametrize("kind,n,seed", [("zipf", 4 << 20, 11), ("dna", 3000017, 12), ("uniform256", (2 << 20) + 5, 13)])
+def test_mid_size_vs_oracle(ctx, kind, n, seed):
+    x = O.generate(kind, n, seed)
+    y = ctx.forward(x)
+    assert np.array_equal(y, O.forward(x))
+    assert np.array_equal(ctx.inverse(y), x)
+
+
+def test_deep_repeats_vs_oracle(ctx):
+    """Long repeats force many doubling rounds and a large active set (real-text shape)."""
+    rng = np.random.default_rng(5)
+    block = rng.integers(97, 101, size=50000, dtype=np.uint8)
+    x = np.concatenate([block, block[:40000], rng.integers(97, 101, size=1000, dtype=np.uint8), block[10000:], block])
+    y = ctx.forward(x)
+    assert ctx.timings().rounds >= 10
+    assert np.array_equal(y, O.forward(x))
+    assert np.array_equal(ctx.inverse(y), x)
+
+
+def test_errors(ctx, pkg):
+    with pytest.raises(pkg.BwtsError) as e:
+        ctx.forward(b"")
+    assert e.value.code == -1          # empty input is an error (reference: map_file.c:36-40)
+    import ctypes
+    assert pkg.lib().bwts_forward_device(ctx._h, None, 10, None) == -1
+    h = ctypes.c_void_p()
+    assert pkg.lib().bwts_ctx_create(ctypes.byref(h), 1 << 20) == -2
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json sizes: size-independent properties
+# ---------------------------------------------------------------------------------------------
+def _properties_at_scale(ctx, kind, n, seed):
+    d_in, d_out, d_back = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    try:
+        ctx.generate(kind, seed, n, d_in)
+        ctx.forward_device(d_in, n, d_out)
+        tf = ctx.timings()
+        # (1) round trip is the identity
+        ctx.inverse_device(d_out, n, d_back)
+        assert ctx.device_equal(d_in, d_back, n)
+        # (2) the transform permutes the input's bytes; (3) bwts[0] = T[n-1]
+        x, y = d_in.download(), d_out.download()
+        assert np.array_equal(np.bincount(x, minlength=256), np.bincount(y, minlength=256))
+        assert y[0] == x[-1]
+        # (4) the generator stream is what the oracle generates (spot check both ends)
+        assert np.array_equal(x[:4096], O.generate(kind, 4096, seed))
+        assert np.array_equal(x[-4096:], O.generate(kind, 4096, seed, off=n - 4096))
+        # (5) bijection the other way: forward(inverse(x)) == x on the same bytes
+        ctx.inverse_device(d_in, n, d_out)
+        ctx.forward_device(d_out, n, d_back)
+        assert ctx.device_equal(d_in, d_back, n)
+        return tf
+    finally:
+        for b in (d_in, d_out, d_back):
+            b.free()
+
+
+def test_config2_uniform_256MiB_properties(ctx):
+    tf = _properties_at_scale(ctx, "uniform256", 1 << 28, 1)
+    assert tf.factors >= 1
+
+
+def test_config3_zipf_1GiB_properties(ctx):
+    _properties_at_scale(ctx, "zipf", 1 << 30, 1)
+
+
+def test_forward_prefix_consistency_64MiB(ctx):
+    """Checksum-of-checksums: 64 MiB zipf forward equals the oracle's (sha256 compared)."""
+    n = 1 << 26
+    x = O.generate("zipf", n, 21)
+    assert hashlib.sha256(ctx.forward(x).tobytes()).hexdigest() == hashlib.sha256(O.forward(x).tobytes()).hexdigest()
+
+
+# ---------------------------------------------------------------------------------------------
+# CLI contract end to end (mk_bwts_sa.c:33-65, unbwts.c:19-92,136-176)
+# ---------------------------------------------------------------------------------------------
+def test_cli_end_to_end(tmp_path):
+    x = O.generate("zipf", 300000, 8)
+    src = tmp_path / "in.txt"
+    x.tofile(src)
+    want = O.forward(x).tobytes()
+    r = subprocess.run([os.path.join(PKG, "mk_bwts"), str(src)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == want                      # no outfile -> stdout
+    out = tmp_path / "out.bwts"
+    r = subprocess.run([os.path.join(PKG, "mk_bwts"), str(src), str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == b"" and out.read_bytes() == want
+    back = tmp_path / "back.txt"
+    r = subprocess.run([os.path.join(PKG, "unbwts"), str(out), str(back)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and back.read_bytes() == x.tobytes()
+    r = subprocess.run([os.path.join(PKG, "unbwts"), str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0
+    line = r.stdout.decode().strip()
+    assert line.startswith("Writing to %s_" % out)                      # unbwts.c:152-158
+    assert open(line[len("Writing to "):], "rb").read() == x.tobytes()
+    r = subprocess.run([os.path.join(PKG, "mk_bwts"), str(src), str(tmp_path / "nodir" / "x")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and r.stderr.decode().startswith("Couldn't open BWTS file for writing")   # mk_bwts_sa.c:55-59
+    env = dict(os.environ, BWTS_TIMINGS="1")
+    r = subprocess.run([os.path.join(PKG, "mk_bwts"), str(src), str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    labels = [l.split(" time ")[0] for l in r.stderr.decode().splitlines() if " time " in l]
+    assert labels[:4] == ["Suffix sort", "Compute ISA", "Fix sort order", "Generate BWTS"]           # mk_bwts_sa.c:50,124,168,190
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
