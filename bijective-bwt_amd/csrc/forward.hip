@@ -3,9 +3,13 @@
 // Replaces divsufsort() + make_bwts_sa() + move_lyndonword_head()
 // (/root/reference/mk_bwts_sa.c:48, :114-195, :74-112).  Instead of suffix-sorting and then
 // patching SA/ISA sequentially, the engine
-//   1. finds the Lyndon factors (prefix minima of suffix ranks, mk_bwts_sa.c:126-129),
+//   1. finds the Lyndon factors.  The reference reads them off the suffix array as the strict
+//      prefix minima of ISA (mk_bwts_sa.c:126-129); the fast path here gets the same set without
+//      a suffix sort: a device-wide prefix-min over packed m-symbol keys leaves a handful of
+//      candidates, which one workgroup settles with exact suffix comparisons.  Inputs with too
+//      many candidates (a^n, (ab)^n ...) take the general path: suffix sort + prefix-min of ISA;
 //   2. sorts all positions directly by their infinite cyclic word rot(p)^omega with prefix
-//      doubling on a CYCLIC successor (no fix-up needed: the result IS the fixed-up order),
+//      doubling on a CYCLIC successor (no fix-up needed: the result IS the fixed-up order);
 //   3. emits bwts[r] = T[cprev(sa[r])] (mk_bwts_sa.c:172-188) as a gather.
 // All index work is u32 with u64 loop bounds; bytes are unsigned.
 #include "internal.h"
@@ -24,12 +28,16 @@
 #define   CNT_ACTIVE   (SM_COUNTERS + 0)
 #define   CNT_SPLITS   (SM_COUNTERS + 1)
 #define   CNT_TOTAL    (SM_COUNTERS + 2)
+#define   CNT_CAND     (SM_COUNTERS + 4)
+#define   CNT_LYN_K    (SM_COUNTERS + 5)
+#define   CNT_LYN_OVF  (SM_COUNTERS + 6)
 
 struct Alphabet {
     int sigma;      // distinct byte values present
     int bits;       // bits per symbol code
     int msym;       // symbols packed into a round-0 key
     int key_bits;   // bits * msym
+    int pad_add;    // added to a table code by the kernels (9-bit padded alphabet only)
 };
 
 static int bitlen_u64(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
@@ -78,12 +86,16 @@ int byte_histogram_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u64 *d_hist256)
     return BWTS_OK;
 }
 
-// builds the byte->code table: cyclic sort uses codes 0..sigma-1, the non-cyclic (suffix)
-// sort reserves code 0 for "past the end" and uses 1..sigma
-static int make_alphabet(bwts_ctx *ctx, const u8 *d_T, u64 n, bool reserve_pad, Alphabet *al)
+// builds the byte->code table from the histogram in h_small: the cyclic sort uses codes
+// 0..sigma-1; the suffix (non-cyclic) sort reserves code 0 for "past the end" and uses 1..sigma
+static int read_histogram(bwts_ctx *ctx, const u8 *d_T, u64 n)
 {
     BWTS_TRY(byte_histogram_device(ctx, d_T, n, ctx->d_small + SM_HIST));
-    BWTS_TRY(read_small(ctx, SM_HIST, 256));
+    return read_small(ctx, SM_HIST, 256);
+}
+
+static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, Alphabet *al)
+{
     u8 codes[256];
     int sigma = 0;
     for (int c = 0; c < 256; c++) {
@@ -95,10 +107,12 @@ static int make_alphabet(bwts_ctx *ctx, const u8 *d_T, u64 n, bool reserve_pad, 
     }
     int ncodes = sigma + (reserve_pad ? 1 : 0);
     int bits = bitlen_u64((u64)(ncodes > 1 ? ncodes - 1 : 1));
+    al->pad_add = 0;
     if (bits > 8) {
-        // 256 symbols + pad: 9-bit codes; the u8 table cannot hold code 256, so the
-        // kernels add the +1 themselves (codes table then holds 0..255)
+        // 256 symbols + pad: 9-bit codes; the u8 table cannot hold code 256, so the kernels add
+        // the +1 themselves (the table then holds 0..255)
         for (int c = 0, s = 0; c < 256; c++) if (ctx->h_small[SM_HIST + c]) codes[c] = (u8)(s++);
+        al->pad_add = 1;
     }
     al->sigma = sigma;
     al->bits = bits;
@@ -108,6 +122,7 @@ static int make_alphabet(bwts_ctx *ctx, const u8 *d_T, u64 n, bool reserve_pad, 
     al->key_bits = al->bits * al->msym;
     memcpy(ctx->h_small + SM_CODES, codes, 256);
     HIPC(hipMemcpyAsync(ctx->d_small + SM_CODES, ctx->h_small + SM_CODES, 256, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));   // h_small is reused by later read-backs
     return BWTS_OK;
 }
 
@@ -129,86 +144,118 @@ __device__ __forceinline__ u64 factor_end(const u32 *__restrict__ fstart, u64 k,
 }
 
 // ------------------------------------------------------------------------------------
-// round 0: key[p] = first msym symbols of the (cyclic | padded) word at p, value = p
+// round 0: key[p] = first msym symbols of the suffix at p (zero-filled past the end), value = p
 // ------------------------------------------------------------------------------------
 #define KB_THREADS 256
 #define KB_ITEMS   8
 #define KB_TILE    (KB_THREADS * KB_ITEMS)
 #define KB_HALO    64
 
-template <bool CYCLIC>
 __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes_g,
                                                                int bits, int msym, int pad_add,
-                                                               const u32 *__restrict__ fstart, u64 k,
                                                                u64 *__restrict__ keys, u32 *__restrict__ vals)
 {
     __shared__ u16 sc[KB_TILE + KB_HALO];
     __shared__ u8 codes[256];
-    __shared__ int fast_flag;
 
     const int tid = threadIdx.x;
     const u64 base = (u64)blockIdx.x * KB_TILE;
     const u64 end = base + KB_TILE < n ? base + KB_TILE : n;
     codes[tid] = codes_g[tid];
-    if (tid == 0) {
-        const u64 last_read = end + (u64)msym - 2;   // index of the last byte any key of this tile reads
-        if (CYCLIC) {
-            const u64 f = factor_of(fstart, k, base);
-            fast_flag = last_read < factor_end(fstart, k, n, f);
-        } else {
-            fast_flag = last_read < n;
-        }
-    }
     __syncthreads();
     const int key_bits = bits * msym;
     const u64 mask = key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull);
 
-    if (fast_flag) {
-        const u32 span = (u32)(end - base) + (u32)msym - 1;
-        for (u32 i = tid; i < span; i += KB_THREADS) sc[i] = (u16)((u32)codes[T[base + i]] + (u32)pad_add);
-        __syncthreads();
-        const u32 o = (u32)tid * KB_ITEMS;
-        if (base + o < end) {
-            u64 key = 0;
-            for (int j = 0; j < msym; j++) key = (key << bits) | sc[o + j];
+    // symbol codes of the tile and its halo; past the end of the text the code is 0
+    const u32 span = (u32)(end - base) + (u32)msym;
+    for (u32 i = tid; i < span; i += KB_THREADS) {
+        const u64 q = base + i;
+        sc[i] = q < n ? (u16)((u32)codes[T[q]] + (u32)pad_add) : (u16)0;
+    }
+    __syncthreads();
+    const u32 o = (u32)tid * KB_ITEMS;
+    if (base + o < end) {
+        u64 key = 0;
+        for (int j = 0; j < msym; j++) key = (key << bits) | sc[o + j];
 #pragma unroll
-            for (int e = 0; e < KB_ITEMS; e++) {
-                const u64 p = base + o + e;
-                if (p < end) {
-                    keys[p] = key;
-                    vals[p] = (u32)p;
-                    key = ((key << bits) | sc[o + e + msym]) & mask;   // sc read stays inside the halo
-                }
-            }
-        }
-    } else {
         for (int e = 0; e < KB_ITEMS; e++) {
-            const u64 p = base + (u64)tid * KB_ITEMS + e;
-            if (p >= end) break;
-            u64 key = 0;
-            if (CYCLIC) {
-                const u64 f = factor_of(fstart, k, p);
-                const u64 s = fstart[f], fe = factor_end(fstart, k, n, f);
-                u64 q = p;
-                for (int j = 0; j < msym; j++) {
-                    key = (key << bits) | (u64)codes[T[q]];
-                    if (++q == fe) q = s;
-                }
-            } else {
-                for (int j = 0; j < msym; j++) {
-                    const u64 q = p + j;
-                    key = (key << bits) | (q < n ? (u64)codes[T[q]] + (u64)pad_add : 0ull);
-                }
+            const u64 p = base + o + e;
+            if (p < end) {
+                keys[p] = key;
+                vals[p] = (u32)p;
+                key = ((key << bits) | sc[o + e + msym]) & mask;   // stays inside the loaded span / halo
             }
-            keys[p] = key;
-            vals[p] = (u32)p;
         }
     }
 }
 
+// first msym symbols of rot(p)^omega for a position of factor [s, e)
+__device__ __forceinline__ u64 cyclic_key(const u8 *__restrict__ T, const u8 *__restrict__ codes, int bits, int msym,
+                                          u64 p, u64 s, u64 e)
+{
+    u64 key = 0, q = p;
+    for (int j = 0; j < msym; j++) {
+        key = (key << bits) | (u64)codes[T[q]];
+        if (++q == e) q = s;
+    }
+    return key;
+}
+
+// positions closer than msym to their factor's end wrap around: rewrite their round-0 keys
+__global__ __launch_bounds__(256) void cyclic_patch_kernel(const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes,
+                                                           int bits, int msym, const u32 *__restrict__ fstart, u64 k,
+                                                           u64 *__restrict__ keys)
+{
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 per = (u64)(msym - 1);
+    if (per == 0 || t >= k * per) return;
+    const u64 f = t / per, j = t % per;
+    const u64 s = fstart[f], e = factor_end(fstart, k, n, f);
+    if (j >= e - s) return;
+    const u64 p = e - 1 - j;
+    keys[p] = cyclic_key(T, codes, bits, msym, p, s, e);
+}
+
 // ------------------------------------------------------------------------------------
-// round with step h: key = (group head, rank of the h-th (cyclic) successor)
+// later rounds: key = (group head, rank of the h-th (cyclic) successor)
 // ------------------------------------------------------------------------------------
+// Round 1 (h = msym): the successor's round-0 rank is its group-head slot = the number of
+// sorted round-0 keys below its own key, found by binary search in the sorted key array, so
+// round 0 never scatters a rank array (n random 4-byte writes).
+template <bool CYCLIC>
+__global__ __launch_bounds__(256) void keybuild_lb_kernel(const u32 *__restrict__ a_idx, const u32 *__restrict__ a_head, u64 a,
+                                                          const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes,
+                                                          int bits, int msym, int pad_add, const u64 *__restrict__ K0, int rb,
+                                                          const u32 *__restrict__ fstart, u64 k, u64 *__restrict__ keys)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a) return;
+    const u64 p = a_idx[i];
+    u64 want;
+    bool past_end = false;
+    if (CYCLIC) {
+        const u64 f = factor_of(fstart, k, p);
+        const u64 s = fstart[f], e = factor_end(fstart, k, n, f), L = e - s;
+        const u64 q = s + ((p - s) + (u64)msym % L) % L;
+        want = cyclic_key(T, codes, bits, msym, q, s, e);
+    } else {
+        const u64 q = p + (u64)msym;
+        past_end = q >= n;
+        want = 0;
+        for (int j = 0; j < msym; j++) {
+            const u64 r = q + j;
+            want = (want << bits) | (r < n ? (u64)codes[T[r]] + (u64)pad_add : 0ull);
+        }
+    }
+    u64 lo = 0, hi = n;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (K0[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    const u64 r2 = CYCLIC ? lo : (past_end ? 0ull : lo + 1ull);
+    keys[i] = ((u64)a_head[i] << rb) | r2;
+}
+
 template <bool CYCLIC>
 __global__ __launch_bounds__(256) void keybuild_h_kernel(const u32 *__restrict__ a_idx, const u32 *__restrict__ a_head, u64 a,
                                                          const u32 *__restrict__ rank, u64 n, u64 h, int rb,
@@ -231,67 +278,72 @@ __global__ __launch_bounds__(256) void keybuild_h_kernel(const u32 *__restrict__
 }
 
 // ------------------------------------------------------------------------------------
-// re-rank: group boundaries of the sorted keys -> new group heads, ranks, suffix array slots
+// re-rank: ONE scan over the sorted keys gives group heads and compacts the still-tied elements
 // ------------------------------------------------------------------------------------
-// slot(i): SA slot of the i-th sorted element (identity in round 0)
-struct HeadIn {
-    const u64 *K; const u32 *S;
-    __device__ __forceinline__ u32 operator()(u64 i) const
+// scan element: high word = slot of a group's first element (max-scan), low word = 1 for an
+// element of a group with more than one member (sum-scan)
+struct OpHeadCount {
+    template <typename T> __device__ __forceinline__ T operator()(T a, T b) const
     {
-        const bool flag = i == 0 || K[i] != K[i - 1];
-        return flag ? (S ? S[i] : (u32)i) : 0u;
+        const u32 ha = (u32)(a >> 32), hb = (u32)(b >> 32);
+        return ((u64)(ha > hb ? ha : hb) << 32) | (u64)(u32)((u32)a + (u32)b);
     }
 };
 
-struct HeadOut {
-    const u64 *K; const u32 *S; const u32 *V; u64 a; int rb;   // rb < 0: round 0 (no old groups)
-    u32 *H; u32 *rank; u32 *SA;
-    u64 *cnt_active, *cnt_splits;
-    __device__ __forceinline__ void operator()(u64 i, u32 head) const
+struct GroupIn {
+    const u64 *K; const u32 *S; u64 a;     // S == nullptr: slot(i) = i (round 0)
+    __device__ __forceinline__ u64 operator()(u64 i) const
     {
         const u64 ki = K[i];
         const bool f0 = i == 0 || ki != K[i - 1];
         const bool f1 = i + 1 == a || K[i + 1] != ki;
-        const u32 v = V[i];
-        H[i] = head;
-        rank[v] = head;
-        if (S) SA[S[i]] = v;
+        const u32 hv = f0 ? (S ? S[i] : (u32)i) : 0u;
+        return ((u64)hv << 32) | (u64)((f0 && f1) ? 0u : 1u);
+    }
+};
+
+struct GroupOut {
+    const u64 *K; const u32 *S; const u32 *V; u64 a; int rb;   // rb < 0: round 0 (no older groups)
+    u32 *rank;                                                  // may be nullptr (ranks not materialised yet)
+    u32 *SA;
+    u32 *n_idx, *n_slot, *n_head;
+    u64 *cnt_active, *cnt_splits;
+    __device__ __forceinline__ void operator()(u64 i, u64 v) const
+    {
+        const u64 ki = K[i];
+        const bool f0 = i == 0 || ki != K[i - 1];
+        const bool f1 = i + 1 == a || K[i + 1] != ki;
         const bool keep = !(f0 && f1);
+        const u32 head = (u32)(v >> 32);
+        const u32 val = V[i];
+        const u32 slot = S ? S[i] : (u32)i;
+        if (rank) rank[val] = head;
+        if (S) SA[slot] = val;
+        if (keep) {
+            const u32 dst = (u32)v - 1u;
+            n_idx[dst] = val; n_slot[dst] = slot; n_head[dst] = head;
+        }
         const bool split = rb >= 0 && i > 0 && f0 && (ki >> rb) == (K[i - 1] >> rb);
         const u64 mk = __ballot(keep), ms = __ballot(split);
-        if (lane_id() == 0) {
+        const u64 act = mk | ms;
+        if (act && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1) {
             if (mk) atomicAdd((unsigned long long *)cnt_active, (unsigned long long)__popcll(mk));
             if (ms) atomicAdd((unsigned long long *)cnt_splits, (unsigned long long)__popcll(ms));
         }
     }
 };
 
-struct KeepIn {
-    const u64 *K; u64 a;
-    __device__ __forceinline__ u32 operator()(u64 i) const
-    {
-        const u64 ki = K[i];
-        const bool f0 = i == 0 || ki != K[i - 1];
-        const bool f1 = i + 1 == a || K[i + 1] != ki;
-        return (f0 && f1) ? 0u : 1u;
-    }
-};
-
-struct KeepOut {
-    const u64 *K; const u32 *S; const u32 *V; const u32 *H; u64 a;
-    u32 *n_idx, *n_slot, *n_head;
-    __device__ __forceinline__ void operator()(u64 i, u32 dst) const
-    {
-        const u64 ki = K[i];
-        const bool f0 = i == 0 || ki != K[i - 1];
-        const bool f1 = i + 1 == a || K[i + 1] != ki;
-        if (!(f0 && f1)) {
-            n_idx[dst] = V[i];
-            n_slot[dst] = S ? S[i] : (u32)i;
-            n_head[dst] = H[i];
-        }
-    }
-};
+// rank[sa[i]] = i for every slot, then rank[idx] = head for the still-tied elements
+__global__ __launch_bounds__(256) void rank_from_sa_kernel(const u32 *__restrict__ SA, u64 n, u32 *__restrict__ rank)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) rank[SA[i]] = (u32)i;
+}
+__global__ __launch_bounds__(256) void rank_from_list_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, u64 a,
+                                                             u32 *__restrict__ rank)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < a) rank[idx[i]] = head[i];
+}
 
 // ------------------------------------------------------------------------------------
 // the doubling sort
@@ -323,132 +375,141 @@ static int sort_space_alloc(bwts_ctx *ctx, u64 n, SortSpace *sp)
     return BWTS_OK;
 }
 
-// aux buffers for the active list; allocated once `a` is known
-struct ActiveSpace {
-    u32 *idx_alt;      // second value buffer of the sort
-    u32 *slot[2];
-    u32 *head[2];
-    u32 *H;
-};
+struct ActiveList { u32 *idx, *slot, *head; };
 
+static int build_ranks(bwts_ctx *ctx, const u32 *SA, u64 n, const ActiveList &l, u64 a, u32 *rank)
+{
+    SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
+    u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+    rank_from_sa_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(SA, n, rank);
+    if (a) rank_from_list_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(l.idx, l.head, a, rank);
+    HIPC(hipGetLastError());
+    return BWTS_OK;
+}
 
+// Sorts all positions by their (cyclic | suffix) word.  sp.keys[0]/sp.vals[0] hold the round-0
+// keys and the identity on entry.  want_ranks: leave final ranks in sp.rank (ISA for the suffix sort).
 template <bool CYCLIC>
 static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, const u32 *d_fstart, u64 k,
-                         SortSpace &sp, u32 **sa_out, u32 *rounds_out, u64 *active0_out)
+                         SortSpace &sp, bool want_ranks, u32 **sa_out, u32 *rounds_out, u64 *active0_out)
 {
     const u8 *d_codes = (const u8 *)(ctx->d_small + SM_CODES);
-    const int pad_add = (!CYCLIC && al.bits > 8) ? 1 : 0;
     u64 *cnt = ctx->d_small + SM_COUNTERS;
 
     // ---- round 0 ------------------------------------------------------------------
-    {
-        SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + 12 * n);
-        const u64 blocks = (n + KB_TILE - 1) / KB_TILE;
-        keybuild0_kernel<CYCLIC><<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(
-            d_T, n, d_codes, al.bits, al.msym, pad_add, d_fstart, k, sp.keys[0], sp.vals[0]);
-        HIPC(hipGetLastError());
-    }
     SortPlan plan;
     plan.keys[0] = sp.keys[0]; plan.keys[1] = sp.keys[1];
     plan.vals[0] = sp.vals[0]; plan.vals[1] = sp.vals[1];
     plan.tile_hist = sp.tile_hist; plan.scan_temp = sp.scan_temp;
     int res = 0;
     BWTS_TRY(radix_sort_pairs(ctx, plan, n, al.key_bits, &res));
-    u64 *K = sp.keys[res];
+    u64 *K0 = sp.keys[res];
     u32 *SA = sp.vals[res];
-    u32 *H0 = sp.vals[res ^ 1];
+    // the other key buffer (8n bytes) and value buffer (4n) are free: first active list goes there
+    ActiveList cur;
+    cur.idx = (u32 *)sp.keys[res ^ 1];
+    cur.slot = cur.idx + n;
+    cur.head = sp.vals[res ^ 1];
 
     HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
     {
-        SpanGuard g(ctx, BWTS_K_RERANK, n, 16 * n);
-        HeadIn in{K, nullptr};
-        HeadOut out{K, nullptr, SA, n, -1, H0, sp.rank, SA, cnt + 0, cnt + 1};
-        BWTS_TRY((device_scan<true, u32>(ctx, n, in, out, OpMax(), 0u, sp.scan_temp)));
+        SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
+        GroupIn in{K0, nullptr, n};
+        GroupOut out{K0, nullptr, SA, n, -1, nullptr, SA, cur.idx, cur.slot, cur.head, cnt + 0, cnt + 1};
+        BWTS_TRY((device_scan<true, u64>(ctx, n, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
     }
     BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
     u64 a = ctx->h_small[CNT_ACTIVE];
     *active0_out = a;
     u32 rounds = 1;
-    if (a == 0) { *sa_out = SA; *rounds_out = rounds; return BWTS_OK; }
+    bool rank_valid = false;
+    ActiveList none{nullptr, nullptr, nullptr};
 
-    // ---- active list ------------------------------------------------------------------
-    ActiveSpace as;
-    {
+    if (a > 0) {
+        if (a > 0xffffffffull) return BWTS_E_RANGE;
+        // aux: two key buffers, one value scratch, two list sets
         char *base = nullptr;
-        const size_t each = align_up((size_t)a * 4, 256);
-        BWTS_TRY(aux_reserve(ctx, 6 * each, &base));
-        as.idx_alt = (u32 *)(base + 0 * each);
-        as.slot[0] = (u32 *)(base + 1 * each);
-        as.slot[1] = (u32 *)(base + 2 * each);
-        as.head[0] = (u32 *)(base + 3 * each);
-        as.head[1] = (u32 *)(base + 4 * each);
-        as.H       = (u32 *)(base + 5 * each);
-    }
-    // the round-0 H buffer doubles as the first value buffer of the active sort once compacted;
-    // compaction reads H0 while writing idx_alt, then the roles are fixed below
-    u32 *idx_buf[2] = {as.idx_alt, H0};
-    int ic = 0, sc = 0;
-    {
-        SpanGuard g(ctx, BWTS_K_RERANK, n, 12 * n);
-        KeepIn in{K, n};
-        KeepOut out{K, nullptr, SA, H0, n, idx_buf[0], as.slot[0], as.head[0]};
-        BWTS_TRY((device_scan<false, u32>(ctx, n, in, out, OpAdd(), 0u, sp.scan_temp)));
-    }
-
-    const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
-    if (2 * rb > 64) return BWTS_E_RANGE;
-    const int round_key_bits = 2 * rb > 1 ? 2 * rb : 1;
-
-    for (u64 h = (u64)al.msym;; h <<= 1) {
-        rounds++;
-        {
-            SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 20 * a);
-            keybuild_h_kernel<CYCLIC><<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-                idx_buf[ic], as.head[sc], a, sp.rank, n, h, rb, d_fstart, k, sp.keys[0]);
-            HIPC(hipGetLastError());
+        const size_t e4 = align_up((size_t)a * 4, 256), e8 = align_up((size_t)a * 8, 256);
+        BWTS_TRY(aux_reserve(ctx, 2 * e8 + 7 * e4, &base));
+        u64 *akeys[2] = {(u64 *)base, (u64 *)(base + e8)};
+        char *q = base + 2 * e8;
+        u32 *scratch = (u32 *)q; q += e4;
+        ActiveList sets[2];
+        for (int s = 0; s < 2; s++) {
+            sets[s].idx = (u32 *)q; q += e4;
+            sets[s].slot = (u32 *)q; q += e4;
+            sets[s].head = (u32 *)q; q += e4;
         }
-        SortPlan ap;
-        ap.keys[0] = sp.keys[0]; ap.keys[1] = sp.keys[1];
-        ap.vals[0] = idx_buf[ic]; ap.vals[1] = idx_buf[ic ^ 1];
-        ap.tile_hist = sp.tile_hist; ap.scan_temp = sp.scan_temp;
-        int r2 = 0;
-        BWTS_TRY(radix_sort_pairs(ctx, ap, a, round_key_bits, &r2));
-        u64 *AK = sp.keys[r2];
-        u32 *AV = r2 ? idx_buf[ic ^ 1] : idx_buf[ic];
-        u32 *AVfree = r2 ? idx_buf[ic] : idx_buf[ic ^ 1];
+        const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
+        if (2 * rb > 64) return BWTS_E_RANGE;
+        const int round_key_bits = 2 * rb > 1 ? 2 * rb : 1;
+        int nxt = 0;
 
-        HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
-        {
-            SpanGuard g(ctx, BWTS_K_RERANK, a, 24 * a);
-            HeadIn in{AK, as.slot[sc]};
-            HeadOut out{AK, as.slot[sc], AV, a, rb, as.H, sp.rank, SA, cnt + 0, cnt + 1};
-            BWTS_TRY((device_scan<true, u32>(ctx, a, in, out, OpMax(), 0u, sp.scan_temp)));
+        for (u64 h = (u64)al.msym;; h <<= 1) {
+            rounds++;
+            {
+                SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 20 * a);
+                const unsigned blocks = (unsigned)((a + 255) / 256);
+                if (!rank_valid)
+                    keybuild_lb_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
+                        cur.idx, cur.head, a, d_T, n, d_codes, al.bits, al.msym, al.pad_add, K0, rb, d_fstart, k, akeys[0]);
+                else
+                    keybuild_h_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
+                        cur.idx, cur.head, a, sp.rank, n, h, rb, d_fstart, k, akeys[0]);
+                HIPC(hipGetLastError());
+            }
+            SortPlan ap;
+            ap.keys[0] = akeys[0]; ap.keys[1] = akeys[1];
+            ap.vals[0] = cur.idx; ap.vals[1] = scratch;
+            ap.tile_hist = sp.tile_hist; ap.scan_temp = sp.scan_temp;
+            int r2 = 0;
+            BWTS_TRY(radix_sort_pairs(ctx, ap, a, round_key_bits, &r2));
+            const u64 *AK = akeys[r2];
+            const u32 *AV = r2 ? scratch : cur.idx;
+
+            HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
+            {
+                SpanGuard g(ctx, BWTS_K_RERANK, a, 24 * a);
+                GroupIn in{AK, cur.slot, a};
+                GroupOut out{AK, cur.slot, AV, a, rb, rank_valid ? sp.rank : nullptr, SA,
+                             sets[nxt].idx, sets[nxt].slot, sets[nxt].head, cnt + 0, cnt + 1};
+                BWTS_TRY((device_scan<true, u64>(ctx, a, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
+            }
+            BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
+            const u64 a_new = ctx->h_small[CNT_ACTIVE];
+            const u64 splits = ctx->h_small[CNT_SPLITS];
+            cur = sets[nxt];
+            nxt ^= 1;
+            a = a_new;
+            if (a == 0) break;
+            if (CYCLIC && splits == 0) break;               // partition stable under doubling: equal infinite words
+            if (!CYCLIC && h >= n) return BWTS_E_INTERNAL;  // suffixes are distinct; cannot happen
+            if (rounds > 80) return BWTS_E_INTERNAL;
+            if (!rank_valid) {
+                // a third round is needed: materialise the rank array once, from the suffix array
+                BWTS_TRY(build_ranks(ctx, SA, n, cur, a, sp.rank));
+                rank_valid = true;
+            }
         }
-        BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
-        const u64 a_new = ctx->h_small[CNT_ACTIVE];
-        const u64 splits = ctx->h_small[CNT_SPLITS];
-        if (a_new == 0) break;
-        if (CYCLIC && splits == 0) break;            // partition stable under doubling: equal infinite words
-        if (!CYCLIC && h >= n) return BWTS_E_INTERNAL; // suffixes are distinct; cannot happen
-        if (rounds > 80) return BWTS_E_INTERNAL;
-        {
-            SpanGuard g(ctx, BWTS_K_RERANK, a, 24 * a);
-            KeepIn in{AK, a};
-            KeepOut out{AK, as.slot[sc], AV, as.H, a, AVfree, as.slot[sc ^ 1], as.head[sc ^ 1]};
-            BWTS_TRY((device_scan<false, u32>(ctx, a, in, out, OpAdd(), 0u, sp.scan_temp)));
-        }
-        // the compacted list now lives in AVfree
-        ic = (AVfree == idx_buf[0]) ? 0 : 1;
-        sc ^= 1;
-        a = a_new;
     }
+    if (want_ranks && !rank_valid) BWTS_TRY(build_ranks(ctx, SA, n, a ? cur : none, a, sp.rank));
     *sa_out = SA;
     *rounds_out = rounds;
     return BWTS_OK;
 }
 
+static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp)
+{
+    SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + 12 * n);
+    const u64 blocks = (n + KB_TILE - 1) / KB_TILE;
+    keybuild0_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(
+        d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, sp.keys[0], sp.vals[0]);
+    HIPC(hipGetLastError());
+    return BWTS_OK;
+}
+
 // ------------------------------------------------------------------------------------
-// Lyndon factors = strict prefix minima of the suffix ranks (mk_bwts_sa.c:126-129)
+// Lyndon factors, general path: strict prefix minima of the suffix ranks (mk_bwts_sa.c:126-129)
 // ------------------------------------------------------------------------------------
 struct RankIn { const u32 *r; __device__ __forceinline__ u32 operator()(u64 i) const { return r[i]; } };
 struct MinFlagOut {
@@ -465,50 +526,223 @@ struct StartOut {
     }
 };
 
-int suffix_sort_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u32 **d_sa, u32 **d_rank, u32 *rounds)
+// suffix sort on the padded alphabet; SA in *d_sa, ISA in sp.rank when want_ranks
+static int suffix_sort_in(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, bool want_ranks, u32 **d_sa, u32 *rounds)
 {
     if (n > 0xffffffffull) return BWTS_E_RANGE;
     Alphabet al;
-    BWTS_TRY(make_alphabet(ctx, d_T, n, true, &al));
+    BWTS_TRY(set_alphabet(ctx, true, &al));
+    BWTS_TRY(launch_keybuild0(ctx, d_T, n, al, sp));
+    u64 active0 = 0;
+    return doubling_sort<false>(ctx, d_T, n, al, nullptr, 0, sp, want_ranks, d_sa, rounds, &active0);
+}
+
+int suffix_sort_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u32 **d_sa, u32 **d_rank, u32 *rounds)
+{
+    BWTS_TRY(read_histogram(ctx, d_T, n));
     SortSpace sp;
     BWTS_TRY(sort_space_alloc(ctx, n, &sp));
-    u64 active0 = 0;
-    BWTS_TRY((doubling_sort<false>(ctx, d_T, n, al, nullptr, 0, sp, d_sa, rounds, &active0)));
+    BWTS_TRY(suffix_sort_in(ctx, d_T, n, sp, true, d_sa, rounds));
     *d_rank = sp.rank;
     return BWTS_OK;
 }
 
-// On return *d_fstart points at k u32 factor starts placed at the arena's current base.
-int lyndon_factors_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u32 **d_fstart, u64 *k_out, u32 *rounds)
+static int lyndon_general(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, u32 **d_fstart, u64 *k_out, u32 *rounds)
 {
-    const size_t mark = ctx->arena_off;
-    u32 *sa = nullptr, *rank = nullptr;
-    BWTS_TRY(suffix_sort_device(ctx, d_T, n, &sa, &rank, rounds));
-    u8 *flag = arena_array<u8>(ctx, n);
-    u32 *starts_tmp = arena_array<u32>(ctx, n);
-    void *tmp = arena_alloc(ctx, scan_temp_bytes(n));
-    if (!flag || !starts_tmp || !tmp) return BWTS_E_NOMEM;
+    u32 *sa = nullptr;
+    BWTS_TRY(suffix_sort_in(ctx, d_T, n, sp, true, &sa, rounds));
+    // the sort's key buffers are free again: flags and the compacted starts live there
+    u8 *flag = (u8 *)sp.keys[0];
+    u32 *starts_tmp = (u32 *)sp.keys[1];
     u64 *total = ctx->d_small + CNT_TOTAL;
     {
         SpanGuard g(ctx, BWTS_K_LYNDON, n, 8 * n);
-        RankIn in{rank};
-        MinFlagOut out{rank, flag};
-        BWTS_TRY((device_scan<false, u32>(ctx, n, in, out, OpMin(), 0xffffffffu, tmp)));
+        RankIn in{sp.rank};
+        MinFlagOut out{sp.rank, flag};
+        BWTS_TRY((device_scan<false, u32>(ctx, n, in, out, OpMin(), 0xffffffffu, sp.scan_temp)));
         FlagIn fin{flag};
         StartOut sout{flag, starts_tmp, n, total};
-        BWTS_TRY((device_scan<false, u32>(ctx, n, fin, sout, OpAdd(), 0u, tmp)));
+        BWTS_TRY((device_scan<false, u32>(ctx, n, fin, sout, OpAdd(), 0u, sp.scan_temp)));
     }
     BWTS_TRY(read_small(ctx, CNT_TOTAL, 1));
     const u64 k = ctx->h_small[CNT_TOTAL];
     if (k == 0 || k > n) return BWTS_E_INTERNAL;
-    // move the list to the front of the arena region this call started at; everything else is released
-    u32 *dst = (u32 *)(ctx->arena + mark);
-    HIPC(hipMemcpyAsync(dst, starts_tmp, k * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));   // regions are disjoint: starts_tmp sits past the sort buffers
-    HIPC(hipStreamSynchronize(ctx->stream));
-    ctx->arena_off = mark + align_up(k * sizeof(u32), 256);
+    u32 *dst = arena_array<u32>(ctx, k);
+    if (!dst) return BWTS_E_NOMEM;
+    HIPC(hipMemcpyAsync(dst, starts_tmp, k * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
     *d_fstart = dst;
     *k_out = k;
     return BWTS_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Lyndon factors, fast path
+// ------------------------------------------------------------------------------------
+// p starts a factor iff its suffix is smaller than every earlier suffix.  With K(p) the packed
+// first msym symbols: K(p) > min_{q<p} K(q) rules p out; K(p) < that minimum (and no zero fill
+// in K(p)) proves it; equality -- or fill -- is settled by an exact comparison with the latest
+// factor start.  Prefix-min scan over the round-0 keys -> candidate list -> one workgroup.
+#define LYN_CAND_CAP   65536ull
+#define LYN_WORK_CAP   (32ull << 20)      // bytes compared by the resolver before it gives up
+
+struct KeyIn { const u64 *K; __device__ __forceinline__ u64 operator()(u64 i) const { return K[i]; } };
+struct CandOut {
+    const u64 *K; u64 n; int msym; u64 *cand; u64 cap; u64 *counter;
+    __device__ __forceinline__ void operator()(u64 i, u64 min_before) const
+    {
+        const u64 ki = K[i];
+        const bool c = i == 0 || ki <= min_before;
+        const u64 m = __ballot(c);
+        if (m == 0) return;
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane_id() == leader) base = atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
+        base = shfl_t((u64)base, leader);
+        if (c) {
+            const u64 at = base + (u64)__popcll(m & lanemask_lt());
+            const bool definite = i == 0 || (ki < min_before && i + (u64)msym <= n);
+            if (at < cap) cand[at] = (i << 1) | (definite ? 1ull : 0ull);
+        }
+    }
+};
+
+// one workgroup walks the position-sorted candidates; exact suffix comparison is block-wide
+__global__ __launch_bounds__(256) void lyndon_resolve_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ cand, u64 cnt,
+                                                             u32 *__restrict__ fstart, u64 *__restrict__ out_k, u64 *__restrict__ out_ovf,
+                                                             u64 work_cap)
+{
+    __shared__ int s_mis[4];      // per wave: first mismatching lane of the chunk, or -1
+    __shared__ int s_less[4];     // per wave: candidate byte < current-start byte at that lane
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    u64 cur = 0, k = 0, work = 0;
+    for (u64 c = 0; c < cnt; c++) {
+        const u64 e = cand[c];
+        const u64 p = e >> 1;
+        bool is_start;
+        if (p == 0 || (e & 1)) {
+            is_start = true;
+        } else {
+            is_start = false;
+            for (u64 off = 0;; off += 256) {
+                const u64 i = off + tid;
+                const int a = p + i < n ? (int)T[p + i] : -1;       // the shorter suffix is the smaller one
+                const int b = cur + i < n ? (int)T[cur + i] : -1;
+                const u64 mm = __ballot(a != b);
+                if (lane == 0) s_mis[w] = mm ? __ffsll((unsigned long long)mm) - 1 : -1;
+                if (mm && lane == __ffsll((unsigned long long)mm) - 1) s_less[w] = a < b;
+                __syncthreads();
+                int found = -1;
+#pragma unroll
+                for (int ww = 3; ww >= 0; ww--) if (s_mis[ww] >= 0) found = ww;
+                const int less = found >= 0 ? s_less[found] : 0;
+                __syncthreads();
+                work += 256;
+                if (found >= 0) { is_start = less != 0; break; }
+                if (work > work_cap) { if (tid == 0) *out_ovf = 1; return; }
+            }
+        }
+        if (is_start) {
+            if (tid == 0) fstart[k] = (u32)p;
+            k++;
+            cur = p;
+        }
+    }
+    if (tid == 0) *out_k = k;
+}
+
+// returns BWTS_OK with *done = false when the input needs the general path
+static int lyndon_fast(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp, u64 *cand[2], u32 *cvals[2],
+                       u32 *fstart, u64 *k_out, bool *done)
+{
+    *done = false;
+    u64 *cnt = ctx->d_small + SM_COUNTERS;
+    HIPC(hipMemsetAsync(cnt + 4, 0, 4 * sizeof(u64), ctx->stream));
+    {
+        SpanGuard g(ctx, BWTS_K_LYNDON, n, 8 * n);
+        KeyIn in{sp.keys[0]};
+        CandOut out{sp.keys[0], n, al.msym, cand[0], LYN_CAND_CAP, ctx->d_small + CNT_CAND};
+        BWTS_TRY((device_scan<false, u64>(ctx, n, in, out, OpMin(), ~0ull, sp.scan_temp)));
+    }
+    BWTS_TRY(read_small(ctx, CNT_CAND, 1));
+    const u64 cnt_c = ctx->h_small[CNT_CAND];
+    if (cnt_c == 0) return BWTS_E_INTERNAL;
+    if (cnt_c > LYN_CAND_CAP) return BWTS_OK;
+    // candidates arrive in arbitrary order: sort by position
+    SortPlan cp;
+    cp.keys[0] = cand[0]; cp.keys[1] = cand[1];
+    cp.vals[0] = cvals[0]; cp.vals[1] = cvals[1];
+    cp.tile_hist = sp.tile_hist; cp.scan_temp = sp.scan_temp;
+    int res = 0;
+    BWTS_TRY(radix_sort_pairs(ctx, cp, cnt_c, bitlen_u64(n) + 1, &res));
+    {
+        SpanGuard g(ctx, BWTS_K_LYNDON, cnt_c, 0);
+        lyndon_resolve_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(d_T, n, cand[res], cnt_c, fstart, ctx->d_small + CNT_LYN_K,
+                                                                    ctx->d_small + CNT_LYN_OVF, LYN_WORK_CAP);
+        HIPC(hipGetLastError());
+    }
+    BWTS_TRY(read_small(ctx, CNT_LYN_K, 2));
+    if (ctx->h_small[CNT_LYN_OVF]) return BWTS_OK;
+    *k_out = ctx->h_small[CNT_LYN_K];
+    if (*k_out == 0) return BWTS_E_INTERNAL;
+    *done = true;
+    return BWTS_OK;
+}
+
+static int lyndon_mode(void)
+{
+    const char *env = getenv("BWTS_LYNDON");     // auto (default) | fast | general
+    if (env && !strcmp(env, "general")) return 2;
+    if (env && !strcmp(env, "fast")) return 1;
+    return 0;
+}
+
+// Finds the factors and leaves the cyclic round-0 keys in sp.keys[0] / identity in sp.vals[0].
+static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, Alphabet *al, u32 **d_fstart, u64 *k_out,
+                            u32 *lyndon_rounds)
+{
+    u64 *cand[2];
+    u32 *cvals[2];
+    for (int i = 0; i < 2; i++) {
+        cand[i] = arena_array<u64>(ctx, LYN_CAND_CAP);
+        cvals[i] = arena_array<u32>(ctx, LYN_CAND_CAP);
+        if (!cand[i] || !cvals[i]) return BWTS_E_NOMEM;
+    }
+    u32 *fast_starts = arena_array<u32>(ctx, LYN_CAND_CAP);
+    if (!fast_starts) return BWTS_E_NOMEM;
+
+    BWTS_TRY(read_histogram(ctx, d_T, n));
+    const int mode = lyndon_mode();
+    bool done = false;
+    *lyndon_rounds = 0;
+    if (mode != 2) {
+        BWTS_TRY(set_alphabet(ctx, false, al));
+        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp));
+        BWTS_TRY(lyndon_fast(ctx, d_T, n, *al, sp, cand, cvals, fast_starts, k_out, &done));
+        if (done) *d_fstart = fast_starts;
+        else if (mode == 1) return BWTS_E_INTERNAL;
+    }
+    if (!done) {
+        BWTS_TRY(lyndon_general(ctx, d_T, n, sp, d_fstart, k_out, lyndon_rounds));
+        BWTS_TRY(set_alphabet(ctx, false, al));
+        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp));
+    }
+    // wrap the keys of positions near their factor's end
+    if (al->msym > 1) {
+        SpanGuard g(ctx, BWTS_K_KEYBUILD, *k_out * (u64)(al->msym - 1), 0);
+        const u64 threads = *k_out * (u64)(al->msym - 1);
+        cyclic_patch_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+            d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al->bits, al->msym, *d_fstart, *k_out, sp.keys[0]);
+        HIPC(hipGetLastError());
+    }
+    return BWTS_OK;
+}
+
+int lyndon_factors_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u32 **d_fstart, u64 *k_out, u32 *rounds)
+{
+    SortSpace sp;
+    BWTS_TRY(sort_space_alloc(ctx, n, &sp));
+    Alphabet al;
+    return factors_and_keys(ctx, d_T, n, sp, &al, d_fstart, k_out, rounds);
 }
 
 // ------------------------------------------------------------------------------------
@@ -540,35 +774,33 @@ __global__ __launch_bounds__(256) void emit_kernel(const u32 *__restrict__ SA, c
 
 size_t forward_arena_bytes(u64 n)
 {
-    // factor list (worst case n entries) + sort space + Lyndon temporaries (flag, starts, scan temp) + P
-    return align_up(n * 4, 256) + sort_space_bytes(n) + align_up(n, 256) + align_up(n * 4, 256) + scan_temp_bytes(n) +
-           align_up(n, 256) + (1 << 16);
+    // candidate buffers + sort space + factor list (general path: up to n entries) + P
+    return 8 * align_up(LYN_CAND_CAP * 8, 256) + sort_space_bytes(n) + align_up(n * 4, 256) + align_up(n, 256) + (1 << 16);
 }
 
 int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
     if (n > 0x100000000ull) return BWTS_E_RANGE;
     BWTS_TRY(arena_reserve(ctx, forward_arena_bytes(n)));
+    SortSpace sp;
+    BWTS_TRY(sort_space_alloc(ctx, n, &sp));
 
-    // 1. Lyndon factors
+    // 1. Lyndon factors + round-0 keys
+    Alphabet al;
     u32 *d_fstart = nullptr;
     u64 k = 0;
     u32 lrounds = 0;
-    BWTS_TRY(lyndon_factors_device(ctx, d_in, n, &d_fstart, &k, &lrounds));
+    BWTS_TRY(factors_and_keys(ctx, d_in, n, sp, &al, &d_fstart, &k, &lrounds));
     ctx->tm.factors = k;
     ctx->tm.lyndon_rounds = lrounds;
-
-    // 2. cyclic sort
-    Alphabet al;
-    BWTS_TRY(make_alphabet(ctx, d_in, n, false, &al));
     ctx->tm.key_symbols = (u32)al.msym;
     ctx->tm.key_bits = (u32)al.key_bits;
-    SortSpace sp;
-    BWTS_TRY(sort_space_alloc(ctx, n, &sp));
+
+    // 2. cyclic sort
     u32 *SA = nullptr;
     u32 rounds = 0;
     u64 active0 = 0;
-    BWTS_TRY((doubling_sort<true>(ctx, d_in, n, al, d_fstart, k, sp, &SA, &rounds, &active0)));
+    BWTS_TRY((doubling_sort<true>(ctx, d_in, n, al, d_fstart, k, sp, false, &SA, &rounds, &active0)));
     ctx->tm.rounds = rounds;
     ctx->tm.active_after_round0 = active0;
 
