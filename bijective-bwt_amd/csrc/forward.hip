@@ -315,7 +315,7 @@ struct GroupOut {
         const bool f1 = i + 1 == a || K[i + 1] != ki;
         const bool keep = !(f0 && f1);
         const u32 head = (u32)(v >> 32);
-        const u32 val = V[i];
+        const u32 val = (keep || rank || S) ? V[i] : 0u;     // round 0 touches the suffix array only for tied elements
         const u32 slot = S ? S[i] : (u32)i;
         if (rank) rank[val] = head;
         if (S) SA[slot] = val;

@@ -11,19 +11,51 @@
 #include "device_utils.h"
 #include "scan_templ.h"
 
-#define RX_THREADS 256
-#define RX_WAVES   (RX_THREADS / 64)
-#define RX_ITEMS   16
-#define RX_TILE    (RX_THREADS * RX_ITEMS)
-#define RX_CHUNK   128          // tiles per column-scan chunk
+#include <stdlib.h>
 
-u64 radix_tiles(u64 m) { return (m + RX_TILE - 1) / RX_TILE; }
+#define RX_CHUNK   128          // tiles per column-scan chunk
+#define RX_XCDS    8
+
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), and each XCD has its own
+// non-coherent L2.  Tile t's run for digit d is followed in memory by tile t+1's run, so the two share a
+// cache line at the seam: give every XCD a CONTIGUOUS range of tiles, walked in dispatch order, so that
+// both halves of a seam line are written through the same L2 close in time and leave it as one full line.
+// Placement only changes speed, never results.
+__device__ __forceinline__ u64 rx_tile_of_block(u64 tiles)
+{
+    const u64 per = (tiles + RX_XCDS - 1) / RX_XCDS;
+    return (u64)(blockIdx.x % RX_XCDS) * per + (u64)(blockIdx.x / RX_XCDS);
+}
+static inline u64 rx_grid(u64 tiles) { return (tiles + RX_XCDS - 1) / RX_XCDS * RX_XCDS; }
+
+// tile shapes compiled in; BWTS_RX_CONFIG picks one at first use (tuning knob)
+struct RxConfig { int threads, items, variant; };   // variant 1: keys and values staged one after the other (half the LDS)
+static const RxConfig kRxConfigs[] = {{256, 16, 0}, {512, 8, 0}, {512, 12, 0}, {1024, 4, 0}, {256, 12, 0}, {1024, 8, 0}, {512, 16, 0},
+                                      {1024, 6, 0}, {512, 16, 1}, {1024, 8, 1}, {256, 16, 1}, {512, 12, 1}, {256, 32, 1}, {512, 20, 1},
+                                      {1024, 16, 1}, {1024, 12, 1}};
+#define RX_NCONFIGS ((int)(sizeof(kRxConfigs) / sizeof(kRxConfigs[0])))
+#define RX_DEFAULT_CONFIG 8
+
+static int rx_config_index(void)
+{
+    static int idx = -1;
+    if (idx < 0) {
+        idx = RX_DEFAULT_CONFIG;
+        const char *env = getenv("BWTS_RX_CONFIG");
+        if (env) { int v = atoi(env); if (v >= 0 && v < RX_NCONFIGS) idx = v; }
+    }
+    return idx;
+}
+static u64 rx_tile(void) { const RxConfig &c = kRxConfigs[rx_config_index()]; return (u64)c.threads * c.items; }
+
+u64 radix_tiles(u64 m) { return (m + rx_tile() - 1) / rx_tile(); }
 
 static inline u64 radix_chunks(u64 tiles) { return (tiles + RX_CHUNK - 1) / RX_CHUNK; }
 
 size_t radix_tile_hist_bytes(u64 m)
 {
-    const u64 tiles = radix_tiles(m);
+    // sized for the smallest compiled tile so the knob never outgrows a caller's buffer
+    const u64 tiles = (m + 3071) / 3072 + 1;
     return align_up((size_t)tiles * 256 * sizeof(u32), 256) +
            align_up((size_t)radix_chunks(tiles) * 256 * sizeof(u32), 256);
 }
@@ -46,9 +78,12 @@ int exclusive_sum_u32(bwts_ctx *ctx, u32 *data, u64 n, void *temp)
 // ------------------------------------------------------------------------------------
 // pass kernels
 // ------------------------------------------------------------------------------------
+template <int RX_THREADS, int RX_ITEMS>
 __global__ __launch_bounds__(RX_THREADS) void radix_hist_kernel(const u64 *__restrict__ keys, u64 m, int shift,
                                                                  u32 *__restrict__ tile_hist)
 {
+    constexpr int RX_WAVES = RX_THREADS / 64;
+    constexpr int RX_TILE = RX_THREADS * RX_ITEMS;
     __shared__ u32 bins[RX_WAVES][256];
     const int tid = threadIdx.x, w = tid >> 6;
     for (int i = tid; i < RX_WAVES * 256; i += RX_THREADS) ((u32 *)bins)[i] = 0;
@@ -63,10 +98,12 @@ __global__ __launch_bounds__(RX_THREADS) void radix_hist_kernel(const u64 *__res
         }
     }
     __syncthreads();
-    u32 s = 0;
+    if (tid < 256) {
+        u32 s = 0;
 #pragma unroll
-    for (int ww = 0; ww < RX_WAVES; ww++) s += bins[ww][tid];
-    tile_hist[(u64)blockIdx.x * 256 + tid] = s;
+        for (int ww = 0; ww < RX_WAVES; ww++) s += bins[ww][tid];
+        tile_hist[(u64)blockIdx.x * 256 + tid] = s;
+    }
 }
 
 // column sums of a chunk of tiles: chunk_sum[d * chunks + c]
@@ -96,19 +133,25 @@ __global__ __launch_bounds__(256) void radix_chunk_apply_kernel(u32 *__restrict_
     }
 }
 
+template <int RX_THREADS, int RX_ITEMS>
 __global__ __launch_bounds__(RX_THREADS) void radix_scatter_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
                                                                     u64 *__restrict__ kout, u32 *__restrict__ vout,
                                                                     const u32 *__restrict__ tile_off, u64 m, int shift)
 {
-    __shared__ u64 skeys[RX_TILE];
-    __shared__ u32 svals[RX_TILE];
-    __shared__ u32 whist[RX_WAVES][256];
-    __shared__ u32 dbase[256];
-    __shared__ u32 gbase[256];
-    __shared__ u32 scan_sm[RX_WAVES];
+    constexpr int RX_WAVES = RX_THREADS / 64;
+    constexpr int RX_TILE = RX_THREADS * RX_ITEMS;
+    extern __shared__ __attribute__((aligned(16))) char rx_smem[];
+    u64 *skeys = (u64 *)rx_smem;                                  // RX_TILE
+    u32 *svals = (u32 *)(skeys + RX_TILE);                        // RX_TILE
+    u32 (*whist)[256] = (u32 (*)[256])(svals + RX_TILE);          // RX_WAVES x 256
+    u32 *dbase = (u32 *)(whist + RX_WAVES);                       // 256
+    u32 *gbase = dbase + 256;                                     // 256
+    u32 *scan_sm = gbase + 256;                                   // RX_WAVES
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const u64 tile_base = (u64)blockIdx.x * RX_TILE;
+    const u64 tile = rx_tile_of_block((m + RX_TILE - 1) / RX_TILE);
+    const u64 tile_base = tile * RX_TILE;
+    if (tile_base >= m) return;                                   // padding block of the XCD-aligned grid
     const u64 wave_base = tile_base + (u64)w * (64 * RX_ITEMS);
     const u64 remain = m - tile_base;
     const u32 tile_count = remain < RX_TILE ? (u32)remain : (u32)RX_TILE;
@@ -143,19 +186,23 @@ __global__ __launch_bounds__(RX_THREADS) void radix_scatter_kernel(const u64 *__
     }
     __syncthreads();
 
-    // per digit: exclusive offsets across waves, then across digits
+    // per digit: exclusive offsets across waves, then across digits (threads 0..255 own a digit)
     {
         u32 run = 0;
+        if (tid < 256) {
 #pragma unroll
-        for (int ww = 0; ww < RX_WAVES; ww++) {
-            const u32 c = whist[ww][tid];
-            whist[ww][tid] = run;
-            run += c;
+            for (int ww = 0; ww < RX_WAVES; ww++) {
+                const u32 c = whist[ww][tid];
+                whist[ww][tid] = run;
+                run += c;
+            }
         }
         u32 total;
         const u32 exc = block_scan_exclusive<u32, OpAdd, RX_WAVES>(run, OpAdd(), 0u, scan_sm, &total);
-        dbase[tid] = exc;
-        gbase[tid] = tile_off[(u64)blockIdx.x * 256 + tid] - exc;
+        if (tid < 256) {
+            dbase[tid] = exc;
+            gbase[tid] = tile_off[tile * 256 + tid] - exc;
+        }
     }
     __syncthreads();
 
@@ -184,9 +231,197 @@ __global__ __launch_bounds__(RX_THREADS) void radix_scatter_kernel(const u64 *__
     }
 }
 
+// Variant 1: the LDS tile holds the keys first and is then reused for the values, and the
+// per-wave digit counters are 16-bit: 8 B of LDS per element instead of 12, so two 8192-element
+// tiles fit a CU and one tile's loads overlap the other's ranking.
+template <int RX_THREADS, int RX_ITEMS, int MINW>
+__global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
+                                                                     u64 *__restrict__ kout, u32 *__restrict__ vout,
+                                                                     const u32 *__restrict__ tile_off, u64 m, int shift)
+{
+    constexpr int RX_WAVES = RX_THREADS / 64;
+    constexpr int RX_TILE = RX_THREADS * RX_ITEMS;
+    extern __shared__ __attribute__((aligned(16))) char rx_smem[];
+    u64 *stage = (u64 *)rx_smem;                                   // RX_TILE keys, later RX_TILE values
+    u32 *dbase = (u32 *)(stage + RX_TILE);                         // 256
+    u32 *gbase = dbase + 256;                                      // 256
+    u32 *scan_sm = gbase + 256;                                    // RX_WAVES (padded to 16)
+    u16 (*whist)[256] = (u16 (*)[256])(scan_sm + 16);              // RX_WAVES x 256
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u64 tile = rx_tile_of_block((m + RX_TILE - 1) / RX_TILE);
+    const u64 tile_base = tile * RX_TILE;
+    if (tile_base >= m) return;                                   // padding block of the XCD-aligned grid
+    const u64 wave_base = tile_base + (u64)w * (64 * RX_ITEMS);
+    const u64 remain = m - tile_base;
+    const u32 tile_count = remain < RX_TILE ? (u32)remain : (u32)RX_TILE;
+
+    for (int i = tid; i < RX_WAVES * 128; i += RX_THREADS) ((u32 *)whist)[i] = 0;
+
+    u64 key[RX_ITEMS];
+    u32 pos[RX_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const u64 i = wave_base + (u64)j * 64 + lane;
+        key[j] = i < m ? kin[i] : ~0ull;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const bool valid = wave_base + (u64)j * 64 + lane < m;
+        const u32 d = (u32)(key[j] >> shift) & 255u;
+        const u64 peers = match_digit8(d, valid);
+        const u32 before = (u32)__popcll(peers & lanemask_lt());
+        const u32 cnt = (u32)__popcll(peers);
+        const u32 prev = whist[w][d];
+        pos[j] = prev + before;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid && before == 0) whist[w][d] = (u16)(prev + cnt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // values are only needed after the keys have left: start their loads now
+    u32 val[RX_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const u64 i = wave_base + (u64)j * 64 + lane;
+        val[j] = i < m ? vin[i] : 0u;
+    }
+    __syncthreads();
+    {
+        u32 run = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int ww = 0; ww < RX_WAVES; ww++) {
+                const u32 c = whist[ww][tid];
+                whist[ww][tid] = (u16)run;
+                run += c;
+            }
+        }
+        u32 total;
+        const u32 exc = block_scan_exclusive<u32, OpAdd, RX_WAVES>(run, OpAdd(), 0u, scan_sm, &total);
+        if (tid < 256) {
+            dbase[tid] = exc;
+            gbase[tid] = tile_off[tile * 256 + tid] - exc;
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const bool valid = wave_base + (u64)j * 64 + lane < m;
+        const u32 d = (u32)(key[j] >> shift) & 255u;
+        pos[j] += dbase[d] + whist[w][d];
+        if (valid) stage[pos[j]] = key[j];
+    }
+    __syncthreads();
+    u32 dst[RX_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const u32 s = (u32)j * RX_THREADS + tid;
+        if (s < tile_count) {
+            const u64 k = stage[s];
+            dst[j] = gbase[(u32)(k >> shift) & 255u] + s;
+            kout[dst[j]] = k;
+        }
+    }
+    __syncthreads();
+    u32 *vstage = (u32 *)stage;
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const bool valid = wave_base + (u64)j * 64 + lane < m;
+        if (valid) vstage[pos[j]] = val[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const u32 s = (u32)j * RX_THREADS + tid;
+        if (s < tile_count) vout[dst[j]] = vstage[s];
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------
+template <int TH, int IT>
+static void launch_hist_t(bwts_ctx *ctx, u64 tiles, const u64 *keys, u64 m, int shift, u32 *tile_hist)
+{
+    radix_hist_kernel<TH, IT><<<dim3((unsigned)tiles), dim3(TH), 0, ctx->stream>>>(keys, m, shift, tile_hist);
+}
+
+template <int TH, int IT>
+static int launch_scatter_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *tile_off,
+                            u64 m, int shift)
+{
+    constexpr size_t lds = (size_t)TH * IT * 12 + (size_t)(TH / 64) * 1024 + 2048 + (size_t)(TH / 64) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPC(hipFuncSetAttribute((const void *)radix_scatter_kernel<TH, IT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    radix_scatter_kernel<TH, IT><<<dim3((unsigned)rx_grid(tiles)), dim3(TH), lds, ctx->stream>>>(kin, vin, kout, vout, tile_off, m, shift);
+    return BWTS_OK;
+}
+
+template <int TH, int IT, int MINW>
+static int launch_scatter2_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *tile_off,
+                             u64 m, int shift)
+{
+    constexpr size_t lds = (size_t)TH * IT * 8 + 2048 + 64 + (size_t)(TH / 64) * 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPC(hipFuncSetAttribute((const void *)radix_scatter2_kernel<TH, IT, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    radix_scatter2_kernel<TH, IT, MINW><<<dim3((unsigned)rx_grid(tiles)), dim3(TH), lds, ctx->stream>>>(kin, vin, kout, vout, tile_off, m, shift);
+    return BWTS_OK;
+}
+
+static void launch_hist(bwts_ctx *ctx, int cfg, u64 tiles, const u64 *keys, u64 m, int shift, u32 *tile_hist)
+{
+    switch (cfg) {
+    case 0: launch_hist_t<256, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 1: launch_hist_t<512, 8>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 2: launch_hist_t<512, 12>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 3: launch_hist_t<1024, 4>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 4: launch_hist_t<256, 12>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 5: launch_hist_t<1024, 8>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 6: launch_hist_t<512, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 7: launch_hist_t<1024, 6>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 8: launch_hist_t<512, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 9: launch_hist_t<1024, 8>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 10: launch_hist_t<256, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 11: launch_hist_t<512, 12>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 12: launch_hist_t<256, 32>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 13: launch_hist_t<512, 20>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 14: launch_hist_t<1024, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
+    default: launch_hist_t<1024, 12>(ctx, tiles, keys, m, shift, tile_hist); break;
+    }
+}
+
+static int launch_scatter(bwts_ctx *ctx, int cfg, u64 tiles, const u64 *kin, const u32 *vin, u64 *kout, u32 *vout,
+                          const u32 *tile_off, u64 m, int shift)
+{
+    switch (cfg) {
+    case 0: return launch_scatter_t<256, 16>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 1: return launch_scatter_t<512, 8>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 2: return launch_scatter_t<512, 12>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 3: return launch_scatter_t<1024, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 4: return launch_scatter_t<256, 12>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 5: return launch_scatter_t<1024, 8>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 6: return launch_scatter_t<512, 16>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 7: return launch_scatter_t<1024, 6>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 8: return launch_scatter2_t<512, 16, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 9: return launch_scatter2_t<1024, 8, 8>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 10: return launch_scatter2_t<256, 16, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 11: return launch_scatter2_t<512, 12, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 12: return launch_scatter2_t<256, 32, 2>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 13: return launch_scatter2_t<512, 20, 2>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 14: return launch_scatter2_t<1024, 16, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    default: return launch_scatter2_t<1024, 12, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    }
+}
+
 // [tile][digit] counts -> global exclusive offsets in digit-major order, in place.
 // tile_hist must be followed by the chunk table (radix_tile_hist_bytes()).
 int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp)
@@ -208,13 +443,14 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
     if (key_bits > 64) key_bits = 64;
     const int passes = (key_bits + 7) / 8;
     const u64 tiles = radix_tiles(m);
+    const int cfg = rx_config_index();
     u32 *tile_hist = plan.tile_hist;
 
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
         {
             SpanGuard g(ctx, BWTS_K_RADIX_HIST, m, 8 * m);
-            radix_hist_kernel<<<dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream>>>(plan.keys[cur], m, shift, tile_hist);
+            launch_hist(ctx, cfg, tiles, plan.keys[cur], m, shift, tile_hist);
         }
         {
             SpanGuard g(ctx, BWTS_K_RADIX_SCAN, tiles * 256, tiles * 256 * 12);
@@ -222,8 +458,8 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
         }
         {
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 24 * m);
-            radix_scatter_kernel<<<dim3((unsigned)tiles), dim3(RX_THREADS), 0, ctx->stream>>>(
-                plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1], plan.vals[cur ^ 1], tile_hist, m, shift);
+            BWTS_TRY(launch_scatter(ctx, cfg, tiles, plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1], plan.vals[cur ^ 1], tile_hist, m,
+                                    shift));
         }
         HIPC(hipGetLastError());
         cur ^= 1;

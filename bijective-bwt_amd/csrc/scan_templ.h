@@ -10,15 +10,17 @@
 
 static inline u64 scan_tiles(u64 n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 
+// Both sweeps touch element i = tile_base + j * SCAN_THREADS + tid (lane-consecutive, coalesced);
+// the ops used here are commutative, so the reduce sweep may combine in that order.
 template <typename T, typename Op, typename InF>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(u64 n, InF in, Op op, T identity, T *partials)
 {
     __shared__ T sm[SCAN_THREADS / 64];
-    const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    const u64 base = (u64)blockIdx.x * SCAN_TILE + threadIdx.x;
     T acc = identity;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
-        const u64 i = base + j;
+        const u64 i = base + (u64)j * SCAN_THREADS;
         if (i < n) acc = op(acc, in(i));
     }
     T inc = wave_scan_inclusive(acc, op);
@@ -47,17 +49,30 @@ __global__ __launch_bounds__(1024) void scan_partials_kernel(u64 count, Op op, T
     }
 }
 
+// LDS slot of tile element e: one pad slot per 8 keeps the blocked (8 per thread) accesses
+// spread over the banks
+#define SCAN_SLOT(e) ((e) + ((e) >> 3))
+
 template <typename T, typename Op, typename InF, typename OutF, bool INCLUSIVE>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(u64 n, InF in, OutF out, Op op, T identity, const T *partials)
 {
     __shared__ T sm[SCAN_THREADS / 64];
-    const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    __shared__ T tile[SCAN_TILE + SCAN_TILE / 8];
+    const u64 tile_base = (u64)blockIdx.x * SCAN_TILE;
+    // striped (coalesced) load -> LDS
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        const u32 e = (u32)j * SCAN_THREADS + threadIdx.x;
+        const u64 i = tile_base + e;
+        tile[SCAN_SLOT(e)] = i < n ? in(i) : identity;
+    }
+    __syncthreads();
+    // blocked scan: thread t owns elements [8t, 8t+8)
     T v[SCAN_ITEMS];
     T acc = identity;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
-        const u64 i = base + j;
-        v[j] = i < n ? in(i) : identity;
+        v[j] = tile[SCAN_SLOT((u32)threadIdx.x * SCAN_ITEMS + j)];
         acc = op(acc, v[j]);
     }
     T tot;
@@ -65,14 +80,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(u64 n, InF in,
     run = op(partials[blockIdx.x], run);
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
-        const u64 i = base + j;
+        const u32 slot = SCAN_SLOT((u32)threadIdx.x * SCAN_ITEMS + j);
         if (INCLUSIVE) {
             run = op(run, v[j]);
-            if (i < n) out(i, run);
+            tile[slot] = run;
         } else {
-            if (i < n) out(i, run);
+            tile[slot] = run;
             run = op(run, v[j]);
         }
+    }
+    __syncthreads();
+    // striped (coalesced) consumer
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        const u32 e = (u32)j * SCAN_THREADS + threadIdx.x;
+        const u64 i = tile_base + e;
+        if (i < n) out(i, tile[SCAN_SLOT(e)]);
     }
 }
 
