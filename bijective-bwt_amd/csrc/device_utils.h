@@ -29,6 +29,12 @@ __device__ __forceinline__ u64 shfl_up_t(u64 v, int d)
     u32 hi = (u32)__shfl_up((int)(u32)(v >> 32), d, 64);
     return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ u64 shfl_down_t(u64 v, int d)
+{
+    u32 lo = (u32)__shfl_down((int)(u32)v, d, 64);
+    u32 hi = (u32)__shfl_down((int)(u32)(v >> 32), d, 64);
+    return ((u64)hi << 32) | lo;
+}
 __device__ __forceinline__ u32 shfl_t(u32 v, int src) { return (u32)__shfl((int)v, src, 64); }
 __device__ __forceinline__ u64 shfl_t(u64 v, int src)
 {

@@ -290,13 +290,30 @@ struct OpHeadCount {
     }
 };
 
+// The scan kernels visit element i = tile_base + j * 256 + tid, so the neighbouring keys K[i-1], K[i+1]
+// sit in the neighbouring lanes: one global load per element, the wave's two edge lanes load theirs.
+__device__ __forceinline__ void group_flags(const u64 *__restrict__ K, u64 i, u64 a, u64 *ki_out, bool *f0, bool *f1, bool *same_old,
+                                            int rb)
+{
+    const u64 ki = K[i];
+    const int lane = lane_id();
+    const u64 act = __ballot(true);                       // lanes that hold an element (the tail tile is ragged)
+    u64 kp = shfl_up_t(ki, 1), kn = shfl_down_t(ki, 1);
+    if (lane == 0 && i > 0) kp = K[i - 1];
+    const bool next_here = lane < 63 && ((act >> ((lane + 1) & 63)) & 1ull);
+    if (!next_here && i + 1 < a) kn = K[i + 1];
+    *f0 = i == 0 || ki != kp;
+    *f1 = i + 1 == a || kn != ki;
+    *same_old = rb >= 0 && i > 0 && (ki >> rb) == (kp >> rb);
+    *ki_out = ki;
+}
+
 struct GroupIn {
     const u64 *K; const u32 *S; u64 a;     // S == nullptr: slot(i) = i (round 0)
     __device__ __forceinline__ u64 operator()(u64 i) const
     {
-        const u64 ki = K[i];
-        const bool f0 = i == 0 || ki != K[i - 1];
-        const bool f1 = i + 1 == a || K[i + 1] != ki;
+        u64 ki; bool f0, f1, so;
+        group_flags(K, i, a, &ki, &f0, &f1, &so, -1);
         const u32 hv = f0 ? (S ? S[i] : (u32)i) : 0u;
         return ((u64)hv << 32) | (u64)((f0 && f1) ? 0u : 1u);
     }
@@ -310,9 +327,8 @@ struct GroupOut {
     u64 *cnt_active, *cnt_splits;
     __device__ __forceinline__ void operator()(u64 i, u64 v) const
     {
-        const u64 ki = K[i];
-        const bool f0 = i == 0 || ki != K[i - 1];
-        const bool f1 = i + 1 == a || K[i + 1] != ki;
+        u64 ki; bool f0, f1, same_old;
+        group_flags(K, i, a, &ki, &f0, &f1, &same_old, rb);
         const bool keep = !(f0 && f1);
         const u32 head = (u32)(v >> 32);
         const u32 val = (keep || rank || S) ? V[i] : 0u;     // round 0 touches the suffix array only for tied elements
@@ -323,12 +339,13 @@ struct GroupOut {
             const u32 dst = (u32)v - 1u;
             n_idx[dst] = val; n_slot[dst] = slot; n_head[dst] = head;
         }
-        const bool split = rb >= 0 && i > 0 && f0 && (ki >> rb) == (K[i - 1] >> rb);
-        const u64 mk = __ballot(keep), ms = __ballot(split);
-        const u64 act = mk | ms;
-        if (act && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1) {
-            if (mk) atomicAdd((unsigned long long *)cnt_active, (unsigned long long)__popcll(mk));
-            if (ms) atomicAdd((unsigned long long *)cnt_splits, (unsigned long long)__popcll(ms));
+        // number of still-tied elements = inclusive count at the last element (no atomics on the n-sized round);
+        // a count of exactly 2^32 wraps to 0 with the last element tied
+        if (i + 1 == a) *cnt_active = ((u32)v == 0u && keep) ? 0x100000000ull : (u64)(u32)v;
+        if (rb >= 0) {
+            const u64 ms = __ballot(f0 && same_old);
+            if (ms && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1)
+                atomicAdd((unsigned long long *)cnt_splits, (unsigned long long)__popcll(ms));
         }
     }
 };
@@ -760,15 +777,16 @@ __global__ __launch_bounds__(256) void prevsym_fix_kernel(const u8 *__restrict__
 }
 __global__ __launch_bounds__(256) void emit_kernel(const u32 *__restrict__ SA, const u8 *__restrict__ P, u64 n, u8 *__restrict__ out)
 {
-    // 4 slots per thread: one packed 4-byte store
+    // 8 slots per thread: two 16-byte index loads, eight independent gathers in flight, one packed 8-byte store
     const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
-    const u64 i = q * 4;
-    if (i + 4 <= n && ((uintptr_t)out & 3) == 0) {
-        const uint4 s = *(const uint4 *)(SA + i);
-        const u32 w = (u32)P[s.x] | ((u32)P[s.y] << 8) | ((u32)P[s.z] << 16) | ((u32)P[s.w] << 24);
-        *(u32 *)(out + i) = w;
+    const u64 i = q * 8;
+    if (i + 8 <= n && ((uintptr_t)out & 7) == 0) {
+        const uint4 s0 = *(const uint4 *)(SA + i), s1 = *(const uint4 *)(SA + i + 4);
+        const u32 b0 = P[s0.x], b1 = P[s0.y], b2 = P[s0.z], b3 = P[s0.w], b4 = P[s1.x], b5 = P[s1.y], b6 = P[s1.z], b7 = P[s1.w];
+        const u32 lo = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24), hi = b4 | (b5 << 8) | (b6 << 16) | (b7 << 24);
+        *(uint2 *)(out + i) = make_uint2(lo, hi);
     } else {
-        for (u64 j = i; j < n && j < i + 4; j++) out[j] = P[SA[j]];
+        for (u64 j = i; j < n && j < i + 8; j++) out[j] = P[SA[j]];
     }
 }
 
@@ -815,8 +833,8 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     }
     {
         SpanGuard g(ctx, BWTS_K_EMIT, n, 6 * n);
-        const u64 quads = (n + 3) / 4;
-        emit_kernel<<<dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, ctx->stream>>>(SA, P, n, d_out);
+        const u64 octs = (n + 7) / 8;
+        emit_kernel<<<dim3((unsigned)((octs + 255) / 256)), dim3(256), 0, ctx->stream>>>(SA, P, n, d_out);
     }
     HIPC(hipGetLastError());
     return BWTS_OK;
