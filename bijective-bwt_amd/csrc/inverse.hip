@@ -5,7 +5,7 @@
 //   :38-43  exclusive scan       -> column scan of the [tile][symbol] table (radix.hip)
 //   :50-52  prev[i]=counts[B[i]]++ (stable LF map) -> lf_hist_kernel + lf_rank_kernel
 //   :66-86  cycle walk, smallest unvisited index first, text written backwards
-//           -> splitter walk (pass 1), reduced-list ranking, splitter walk (pass 2, emit)
+//           -> splitter walk (pass 1), reduced-list ranking by pointer jumping, splitter walk (pass 2, emit)
 // The reference follows ONE cycle at a time (n dependent loads).  Here every G-th index is a
 // splitter; a lane walks from its splitter to the next one, so ~n/G walks run concurrently.
 // Cycles that contain no splitter are found from the visited marks and resolved separately.
@@ -185,32 +185,128 @@ __global__ __launch_bounds__(256) void walk_emit_kernel(const u32 *__restrict__ 
     }
 }
 
-// unvisited elements (no mark) -> compact list of indices, and their LF values
-struct UnvIn { const u32 *LF; __device__ __forceinline__ u32 operator()(u64 i) const { return (LF[i] & LF_TOP) ? 0u : 1u; } };
-struct UnvOut {
-    const u32 *LF; u32 *uidx; u32 *ulf; u64 n; u64 cap; u64 *total;
-    __device__ __forceinline__ void operator()(u64 i, u32 dst) const
-    {
-        const u32 v = LF[i];
-        const bool un = !(v & LF_TOP);
-        if (un && dst < cap) { uidx[dst] = (u32)i; ulf[dst] = v; }
-        if (i + 1 == n) *total = (u64)dst + (un ? 1 : 0);
-    }
-};
-struct UnvCountIn { const u32 *LF; __device__ __forceinline__ u64 operator()(u64 i) const { return (LF[i] & LF_TOP) ? 0ull : 1ull; } };
-
-__global__ __launch_bounds__(256) void count_unvisited_kernel(const u32 *__restrict__ LF, u64 n, unsigned long long *__restrict__ total)
+// ------------------------------------------------------------------------------------
+// elements no walk reached (cycles without a splitter): one sweep, wave-aggregated append
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void collect_unvisited_kernel(const u32 *__restrict__ LF, u64 n, u32 *__restrict__ uidx,
+                                                                u32 *__restrict__ ulf, u64 cap, unsigned long long *__restrict__ count)
 {
-    u64 c = 0;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) c += (LF[i] & LF_TOP) ? 0 : 1;
-    c = wave_scan_inclusive(c, OpAdd());
-    if (lane_id() == 63 && c) atomicAdd(total, (unsigned long long)c);
+    for (u64 base = (u64)blockIdx.x * 256; base < n; base += (u64)gridDim.x * 256) {
+        const u64 i = base + threadIdx.x;
+        const u32 v = i < n ? LF[i] : LF_TOP;
+        const bool un = !(v & LF_TOP);
+        const u64 m = __ballot(un);
+        if (m) {
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            unsigned long long b = 0;
+            if (lane_id() == leader) b = atomicAdd(count, (unsigned long long)__popcll(m));
+            b = shfl_t((u64)b, leader);
+            if (un) {
+                const u64 at = b + (u64)__popcll(m & lanemask_lt());
+                if (at < cap) { uidx[at] = (u32)i; ulf[at] = v; }
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void scatter_bytes_kernel(const u32 *__restrict__ pos, const u8 *__restrict__ sym, u64 m, u8 *__restrict__ out)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i < m) out[pos[i]] = sym[i];
+}
+
+// ------------------------------------------------------------------------------------
+// reduced-list ranking (splitter nodes) by pointer jumping
+// ------------------------------------------------------------------------------------
+// node v: nxt[v] next splitter on its cycle, len[v] elements in its segment, mn[v] smallest element of the
+// segment and off[v] its distance from the splitter.  Wanted per node: its cycle's leader (smallest node
+// id), length, smallest element, and the node's distance from that smallest element along LF.
+#define LR_NIL 0xffffffffu
+
+__global__ __launch_bounds__(256) void lr_init_kernel(u64 s, const u32 *__restrict__ nxt, const u32 *__restrict__ mn,
+                                                      u32 *__restrict__ lead, u32 *__restrict__ cmin, u32 *__restrict__ hop)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v < s) { lead[v] = (u32)v; cmin[v] = mn[v]; hop[v] = nxt[v]; }
+}
+
+// after r rounds a node has folded in the 2^r nodes that follow it
+__global__ __launch_bounds__(256) void lr_jump_min_kernel(u64 s, const u32 *__restrict__ lead_in, const u32 *__restrict__ cmin_in,
+                                                          const u32 *__restrict__ hop_in, u32 *__restrict__ lead_out,
+                                                          u32 *__restrict__ cmin_out, u32 *__restrict__ hop_out)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= s) return;
+    const u32 h = hop_in[v];
+    const u32 l0 = lead_in[v], l1 = lead_in[h], c0 = cmin_in[v], c1 = cmin_in[h];
+    lead_out[v] = l0 < l1 ? l0 : l1;
+    cmin_out[v] = c0 < c1 ? c0 : c1;
+    hop_out[v] = hop_in[h];
+}
+
+// cut every cycle in front of its leader, then suffix sums of the segment lengths
+__global__ __launch_bounds__(256) void lr_cut_kernel(u64 s, const u32 *__restrict__ nxt, const u32 *__restrict__ len,
+                                                     const u32 *__restrict__ lead, u32 *__restrict__ sum, u32 *__restrict__ hop)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v < s) { sum[v] = len[v]; hop[v] = nxt[v] == lead[v] ? LR_NIL : nxt[v]; }
+}
+
+__global__ __launch_bounds__(256) void lr_jump_sum_kernel(u64 s, const u32 *__restrict__ sum_in, const u32 *__restrict__ hop_in,
+                                                          u32 *__restrict__ sum_out, u32 *__restrict__ hop_out)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= s) return;
+    const u32 h = hop_in[v];
+    if (h == LR_NIL) { sum_out[v] = sum_in[v]; hop_out[v] = LR_NIL; }
+    else { sum_out[v] = sum_in[v] + sum_in[h]; hop_out[v] = hop_in[h]; }
+}
+
+struct CycleRec { u32 leader; u32 minelem; u32 len; u32 pad; };
+
+// dist[v] = elements between the leader's splitter and v's splitter; the node whose segment holds the
+// cycle's smallest element publishes that element's distance; leaders append a cycle record
+__global__ __launch_bounds__(256) void lr_finish_kernel(u64 s, const u32 *__restrict__ lead, const u32 *__restrict__ cmin,
+                                                        const u32 *__restrict__ sum, const u32 *__restrict__ mn,
+                                                        const u32 *__restrict__ off, u32 *__restrict__ dist,
+                                                        u32 *__restrict__ min_dist /* by leader */, CycleRec *__restrict__ recs,
+                                                        unsigned long long *__restrict__ nrec)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= s) return;
+    const u32 l = lead[v];
+    const u32 L = sum[l];
+    const u32 d = L - sum[v];
+    dist[v] = d;
+    if (mn[v] == cmin[v]) min_dist[l] = d + off[v];
+    if (l == (u32)v) {
+        const unsigned long long at = atomicAdd(nrec, 1ull);
+        CycleRec r; r.leader = l; r.minelem = cmin[v]; r.len = L; r.pad = 0;
+        recs[at] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void lr_place_kernel(u64 s, const u32 *__restrict__ lead, const u32 *__restrict__ sum,
+                                                       const u32 *__restrict__ dist, const u32 *__restrict__ min_dist,
+                                                       const u32 *__restrict__ end_by_leader, u32 *__restrict__ opos,
+                                                       u32 *__restrict__ wrap_at, u32 *__restrict__ cyc_len)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= s) return;
+    const u32 l = lead[v];
+    const u32 L = sum[l];
+    const u32 dm = min_dist[l];
+    const u32 d = dist[v];
+    const u32 t = d >= dm ? d - dm : d + L - dm;     // distance of v's splitter from the cycle's smallest element
+    opos[v] = end_by_leader[l] - t;
+    wrap_at[v] = L - t;
+    cyc_len[v] = L;
+}
+
+__global__ __launch_bounds__(256) void scatter_u32_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ val, u64 m, u32 *__restrict__ out)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) out[idx[i]] = val[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -223,48 +319,54 @@ static int splitter_log2(u64 n)
     if (g < 4) g = 4;
     if (g > 10) g = 10;
     const char *env = getenv("BWTS_SPLIT_LOG2");
-    if (env) { int v = atoi(env); if (v >= 1 && v <= 20) g = v; }
+    if (env) { int v = atoi(env); if (v >= 0 && v <= 20) g = v; }
     return g;
 }
 
+#define UNV_CAP (1ull << 20)     // unvisited elements collected by the single sweep
+
 size_t inverse_arena_bytes(u64 n)
 {
-    const u64 tiles = (n + LF_TILE - 1) / LF_TILE;
     const u64 s = (n >> 4) + 2;   // upper bound on splitters (g >= 4)
-    return align_up(n * 4, 256) + radix_tile_hist_bytes(n) + align_up(tiles * 1024, 256) + scan_temp_bytes(n) +
-           8 * align_up(s * 4, 256) + align_up(n * 8, 256) /* worst-case unvisited lists */ + (1 << 16);
+    return align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 24 * align_up(s * 4, 256) + (1 << 16);
 }
 
-struct CycleRec { u32 minelem; u32 len; };
+static int grid1(u64 m) { return (int)((m + 255) / 256); }
 
-int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
+// One attempt with splitter spacing 2^g.  *retry is set when more elements sit in splitter-free cycles than
+// the sweep collects; the caller then repeats with g = 0 (every element a splitter: plain pointer jumping).
+static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int g, bool *retry)
 {
-    if (n >= 0x80000000ull) return BWTS_E_RANGE;
-    const int g = splitter_log2(n);
+    *retry = false;
     const u64 G = 1ull << g;
     const u64 s = (n + G - 1) / G;
     const u64 tiles = (n + LF_TILE - 1) / LF_TILE;
 
-    // arena: LF, tile table, node arrays; unvisited lists are sized once their count is known
-    size_t base_bytes = align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 8 * align_up(s * 4, 256) + (1 << 16);
-    BWTS_TRY(arena_reserve(ctx, base_bytes));
+    const size_t s4 = align_up(s * 4, 256);
+    BWTS_TRY(arena_reserve(ctx, align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 24 * s4 +
+                                    align_up(s * sizeof(CycleRec), 256) + (1 << 16)));
     u32 *LF = arena_array<u32>(ctx, n);
     u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
     void *scan_temp = arena_alloc(ctx, scan_temp_bytes(n));
-    u32 *nxt = arena_array<u32>(ctx, s), *seglen = arena_array<u32>(ctx, s), *segmin = arena_array<u32>(ctx, s),
-        *segoff = arena_array<u32>(ctx, s);
-    u32 *d_opos = arena_array<u32>(ctx, s), *d_wrap = arena_array<u32>(ctx, s), *d_clen = arena_array<u32>(ctx, s);
-    if (!LF || !tile_hist || !scan_temp || !nxt || !seglen || !segmin || !segoff || !d_opos || !d_wrap || !d_clen) return BWTS_E_NOMEM;
+    u32 *node[20];
+    for (int i = 0; i < 20; i++) node[i] = arena_array<u32>(ctx, s);
+    CycleRec *d_recs = (CycleRec *)arena_alloc(ctx, s * sizeof(CycleRec));
+    if (!LF || !tile_hist || !scan_temp || !node[19] || !d_recs) return BWTS_E_NOMEM;
+    u32 *nxt = node[0], *seglen = node[1], *segmin = node[2], *segoff = node[3];
+    u32 *d_opos = node[4], *d_wrap = node[5], *d_clen = node[6];
+    u32 *lead[2] = {node[7], node[8]}, *cmin[2] = {node[9], node[10]}, *hop[2] = {node[11], node[12]};
+    u32 *sum[2] = {node[13], node[14]}, *dist = node[15], *min_dist = node[16], *end_by_leader = node[17];
+    u32 *tmp_idx = node[18], *tmp_val = node[19];
 
     // symbol boundaries C[0..256] on the host (unbwts.c:38-43)
     BWTS_TRY(byte_histogram_device(ctx, d_in, n, ctx->d_small + SMI_HIST));
     BWTS_TRY(read_small(ctx, SMI_HIST, 256));
     u32 *hC = (u32 *)(ctx->h_small + 1024);
     {
-        u64 sum = 0;
-        for (int c = 0; c < 256; c++) { hC[c] = (u32)sum; sum += ctx->h_small[SMI_HIST + c]; }
-        hC[256] = (u32)sum;
-        if (sum != n) return BWTS_E_INTERNAL;
+        u64 acc = 0;
+        for (int c = 0; c < 256; c++) { hC[c] = (u32)acc; acc += ctx->h_small[SMI_HIST + c]; }
+        hC[256] = (u32)acc;
+        if (acc != n) return BWTS_E_INTERNAL;
     }
     u32 *dC = (u32 *)(ctx->d_small + 1024);
     HIPC(hipMemcpyAsync(dC, hC, 257 * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
@@ -280,123 +382,118 @@ int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 
     // pass 1: walk + mark
     unsigned long long *ticket = (unsigned long long *)(ctx->d_small + SMI_COUNTERS);
-    HIPC(hipMemsetAsync(ticket, 0, 4 * sizeof(u64), ctx->stream));
-    u64 walkers = s < 524288 ? s : 524288;
+    HIPC(hipMemsetAsync(ticket, 0, 8 * sizeof(u64), ctx->stream));
+    const u64 walkers = s < 524288 ? s : 524288;
     const unsigned wblocks = (unsigned)((walkers + 255) / 256);
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 4 * n);
         walk_mark_kernel<<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, s, g, nxt, seglen, segmin, segoff, ticket);
         HIPC(hipGetLastError());
     }
-    // unvisited count
+
+    // elements in splitter-free cycles
+    char *ub = nullptr;
+    BWTS_TRY(aux_reserve(ctx, 2 * align_up(UNV_CAP * 4, 256) + align_up(UNV_CAP, 256), &ub));
+    u32 *uidx = (u32 *)ub, *ulf = (u32 *)(ub + align_up(UNV_CAP * 4, 256));
     {
         SpanGuard sg(ctx, BWTS_K_OTHER, n, 4 * n);
-        u64 blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
-        count_unvisited_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, n, ticket + 1);
+        u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+        collect_unvisited_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, n, uidx, ulf, UNV_CAP, ticket + 1);
         HIPC(hipGetLastError());
+    }
+
+    // reduced-list ranking on the device
+    const int R = [&] { int b = 0; for (u64 x = s; x; x >>= 1) b++; return b; }();   // 2^R > s >= any cycle's node count
+    int cur = 0;
+    {
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, s, 0);
+        const int gb = grid1(s);
+        lr_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, nxt, segmin, lead[0], cmin[0], hop[0]);
+        for (int r = 0; r < R; r++, cur ^= 1)
+            lr_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, lead[cur], cmin[cur], hop[cur], lead[cur ^ 1], cmin[cur ^ 1], hop[cur ^ 1]);
+        u32 *leadf = lead[cur], *cminf = cmin[cur];
+        int sc = 0;
+        lr_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, nxt, seglen, leadf, sum[0], hop[0]);
+        int hc = 0;
+        u32 *hopb[2] = {hop[0], hop[1]};
+        for (int r = 0; r < R; r++, sc ^= 1, hc ^= 1)
+            lr_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, sum[sc], hopb[hc], sum[sc ^ 1], hopb[hc ^ 1]);
+        lr_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, leadf, cminf, sum[sc], segmin, segoff, dist, min_dist, d_recs, ticket + 2);
+        HIPC(hipGetLastError());
+        // keep the final buffers' identities for the placement kernel
+        lead[0] = leadf; sum[0] = sum[sc];
     }
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 4));
     const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
+    const u64 kc = ctx->h_small[SMI_COUNTERS + 2];
     ctx->tm.unvisited = nu;
+    if (kc == 0 || kc > s) return BWTS_E_INTERNAL;
+    if (nu > UNV_CAP) { *retry = true; return BWTS_OK; }   // Theta(n) elements in tiny cycles
 
-    // reduced list to the host
-    std::vector<u32> h_nxt(s), h_len(s), h_min(s), h_off(s);
-    HIPC(hipMemcpyAsync(h_nxt.data(), nxt, s * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipMemcpyAsync(h_len.data(), seglen, s * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipMemcpyAsync(h_min.data(), segmin, s * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(hipMemcpyAsync(h_off.data(), segoff, s * 4, hipMemcpyDeviceToHost, ctx->stream));
-
-    std::vector<u32> h_uidx, h_ulf;
+    // host: order the cycles by smallest element (unbwts.c:62-77); splitter-free cycles join here
+    std::vector<CycleRec> recs(kc);
+    HIPC(hipMemcpyAsync(recs.data(), d_recs, kc * sizeof(CycleRec), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<u32> h_uidx(nu), h_ulf(nu);
     if (nu) {
-        char *ub = nullptr;
-        const size_t each = align_up((size_t)nu * 4, 256);
-        BWTS_TRY(aux_reserve(ctx, 2 * each + align_up((size_t)nu, 256), &ub));
-        u32 *uidx = (u32 *)ub, *ulf = (u32 *)(ub + each);
-        {
-            SpanGuard sg(ctx, BWTS_K_OTHER, n, 4 * n);
-            UnvIn in{LF};
-            UnvOut out{LF, uidx, ulf, n, nu, ctx->d_small + SMI_COUNTERS + 2};
-            BWTS_TRY((device_scan<false, u32>(ctx, n, in, out, OpAdd(), 0u, scan_temp)));
-        }
-        h_uidx.resize(nu); h_ulf.resize(nu);
         HIPC(hipMemcpyAsync(h_uidx.data(), uidx, nu * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPC(hipMemcpyAsync(h_ulf.data(), ulf, nu * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPC(hipStreamSynchronize(ctx->stream));
 
-    // ---- host: rank the reduced list (BWTS_K_LISTRANK on the host for now) --------------
-    // per cycle: smallest element, length; per node: distance from the cycle's smallest element
-    std::vector<CycleRec> cycles;
-    std::vector<u32> node_cyc(s), node_t(s);
-    {
-        std::vector<u8> seen(s, 0);
-        std::vector<u64> dist;   // scratch per cycle
-        std::vector<u32> members;
-        for (u64 v = 0; v < s; v++) {
-            if (seen[v]) continue;
-            members.clear(); dist.clear();
-            u64 total = 0, best_d = 0;
-            u32 best = 0xffffffffu;
-            u64 u = v;
-            do {
-                seen[u] = 1;
-                members.push_back((u32)u);
-                dist.push_back(total);
-                if (h_min[u] < best) { best = h_min[u]; best_d = total + h_off[u]; }
-                total += h_len[u];
-                u = h_nxt[u];
-                if (u >= s) return BWTS_E_INTERNAL;
-            } while (u != v);
-            const u32 cid = (u32)cycles.size();
-            cycles.push_back(CycleRec{best, (u32)total});
-            for (size_t q = 0; q < members.size(); q++) {
-                const u64 t = (dist[q] + total - best_d) % total;
-                node_cyc[members[q]] = cid;
-                node_t[members[q]] = (u32)t;
-            }
-        }
-    }
-    // cycles made only of unvisited elements
+    struct Cyc { u32 minelem, len; u32 leader; };   // leader = LR_NIL for a splitter-free cycle
+    std::vector<Cyc> cycles;
+    cycles.reserve(kc + 16);
+    for (const CycleRec &r : recs) cycles.push_back(Cyc{r.minelem, r.len, r.leader});
     std::vector<u32> u_cyc(nu), u_t(nu);
     if (nu) {
+        // the sweep appends in arbitrary order: sort (index, LF) pairs by index
+        std::vector<u32> ord(nu);
+        for (u64 q = 0; q < nu; q++) ord[q] = (u32)q;
+        std::sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return h_uidx[a] < h_uidx[b]; });
+        std::vector<u32> si(nu), sl(nu);
+        for (u64 q = 0; q < nu; q++) { si[q] = h_uidx[ord[q]]; sl[q] = h_ulf[ord[q]]; }
+        h_uidx.swap(si); h_ulf.swap(sl);
         std::vector<u8> seen(nu, 0);
         for (u64 q = 0; q < nu; q++) {
             if (seen[q]) continue;
             const u32 cid = (u32)cycles.size();
-            u64 cur = q;
+            u64 at = q;
             u32 t = 0;
             do {
-                seen[cur] = 1;
-                u_cyc[cur] = cid; u_t[cur] = t++;
-                const u32 nx = h_ulf[cur];
+                seen[at] = 1;
+                u_cyc[at] = cid; u_t[at] = t++;
+                const u32 nx = h_ulf[at];
                 const auto it = std::lower_bound(h_uidx.begin(), h_uidx.end(), nx);
                 if (it == h_uidx.end() || *it != nx) return BWTS_E_INTERNAL;
-                cur = (u64)(it - h_uidx.begin());
-            } while (cur != q);
-            cycles.push_back(CycleRec{h_uidx[q], t});
+                at = (u64)(it - h_uidx.begin());
+            } while (at != q);
+            cycles.push_back(Cyc{h_uidx[q], t, LR_NIL});
         }
     }
     ctx->tm.factors = cycles.size();
-    // order cycles by smallest element: the first one ends the text (unbwts.c:62-77)
     std::vector<u32> order(cycles.size());
     for (size_t c = 0; c < order.size(); c++) order[c] = (u32)c;
     std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return cycles[a].minelem < cycles[b].minelem; });
-    std::vector<u64> cyc_end(cycles.size());
+    std::vector<u32> cyc_end(cycles.size());
+    std::vector<u32> h_lidx, h_lend;
+    h_lidx.reserve(kc); h_lend.reserve(kc);
     {
         u64 used = 0;
-        for (u32 c : order) { cyc_end[c] = n - 1 - used; used += cycles[c].len; }
+        for (u32 c : order) {
+            cyc_end[c] = (u32)(n - 1 - used);
+            used += cycles[c].len;
+            if (cycles[c].leader != LR_NIL) { h_lidx.push_back(cycles[c].leader); h_lend.push_back(cyc_end[c]); }
+        }
         if (used != n) return BWTS_E_INTERNAL;
     }
-    std::vector<u32> h_opos(s), h_wrap(s), h_clen(s);
-    for (u64 v = 0; v < s; v++) {
-        const u32 c = node_cyc[v];
-        h_opos[v] = (u32)(cyc_end[c] - node_t[v]);
-        h_wrap[v] = cycles[c].len - node_t[v];
-        h_clen[v] = cycles[c].len;
+    HIPC(hipMemcpyAsync(tmp_idx, h_lidx.data(), kc * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipMemcpyAsync(tmp_val, h_lend.data(), kc * 4, hipMemcpyHostToDevice, ctx->stream));
+    {
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, s, 0);
+        scatter_u32_kernel<<<dim3(grid1(kc)), dim3(256), 0, ctx->stream>>>(tmp_idx, tmp_val, kc, end_by_leader);
+        lr_place_kernel<<<dim3(grid1(s)), dim3(256), 0, ctx->stream>>>(s, lead[0], sum[0], dist, min_dist, end_by_leader, d_opos, d_wrap, d_clen);
+        HIPC(hipGetLastError());
     }
-    HIPC(hipMemcpyAsync(d_opos, h_opos.data(), s * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPC(hipMemcpyAsync(d_wrap, h_wrap.data(), s * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPC(hipMemcpyAsync(d_clen, h_clen.data(), s * 4, hipMemcpyHostToDevice, ctx->stream));
 
     // pass 2: walk + emit (unbwts.c:73-82)
     HIPC(hipMemsetAsync(ticket, 0, sizeof(u64), ctx->stream));
@@ -411,20 +508,29 @@ int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     if (nu) {
         h_upos.resize(nu); h_usym.resize(nu);
         for (u64 q = 0; q < nu; q++) {
-            h_upos[q] = (u32)(cyc_end[u_cyc[q]] - u_t[q]);
-            const u32 y = h_ulf[q];
-            const u32 *it = std::upper_bound(hC, hC + 257, y);
+            h_upos[q] = cyc_end[u_cyc[q]] - u_t[q];
+            const u32 *it = std::upper_bound(hC, hC + 257, h_ulf[q]);
             h_usym[q] = (u8)((it - hC) - 1);
         }
-        char *ub = ctx->aux;
-        const size_t each = align_up((size_t)nu * 4, 256);
-        u32 *d_upos = (u32 *)ub;               // uidx no longer needed
-        u8 *d_usym = (u8 *)(ub + 2 * each);
+        u32 *d_upos = uidx;                                           // the index list is no longer needed
+        u8 *d_usym = (u8 *)(ub + 2 * align_up(UNV_CAP * 4, 256));
         HIPC(hipMemcpyAsync(d_upos, h_upos.data(), nu * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPC(hipMemcpyAsync(d_usym, h_usym.data(), nu, hipMemcpyHostToDevice, ctx->stream));
-        scatter_bytes_kernel<<<dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_upos, d_usym, nu, d_out);
+        scatter_bytes_kernel<<<dim3(grid1(nu)), dim3(256), 0, ctx->stream>>>(d_upos, d_usym, nu, d_out);
         HIPC(hipGetLastError());
     }
     HIPC(hipStreamSynchronize(ctx->stream));   // host vectors above must outlive the copies
+    return BWTS_OK;
+}
+
+int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
+{
+    if (n >= 0x80000000ull) return BWTS_E_RANGE;
+    bool retry = false;
+    BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), &retry));
+    if (retry) {
+        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, &retry));
+        if (retry) return BWTS_E_INTERNAL;
+    }
     return BWTS_OK;
 }

@@ -139,6 +139,18 @@ def test_deep_repeats_vs_oracle(ctx):
     assert np.array_equal(ctx.inverse(y), x)
 
 
+def test_inverse_many_tiny_cycles(ctx):
+    """Theta(n) LF cycles without a splitter: the engine falls back to plain pointer jumping (g = 0)."""
+    x = np.sort(O.generate("zipf", 3 << 20, 2))          # sorted bytes: LF is the identity, n cycles of length 1
+    got = ctx.inverse(x)
+    assert ctx.timings().unvisited == 0                  # second attempt: every element is a splitter
+    assert np.array_equal(got, O.inverse(x))
+    y = np.frombuffer(b"ba" * (1 << 20), dtype=np.uint8)  # forward gives 2^20 factors of length 2
+    f = ctx.forward(y)
+    assert np.array_equal(f, O.forward(y))
+    assert np.array_equal(ctx.inverse(f), y)
+
+
 def test_errors(ctx, pkg):
     with pytest.raises(pkg.BwtsError) as e:
         ctx.forward(b"")
