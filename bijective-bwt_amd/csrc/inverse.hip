@@ -5,10 +5,11 @@
 //   :38-43  exclusive scan       -> column scan of the [tile][symbol] table (radix.hip)
 //   :50-52  prev[i]=counts[B[i]]++ (stable LF map) -> lf_hist_kernel + lf_rank_kernel
 //   :66-86  cycle walk, smallest unvisited index first, text written backwards
-//           -> splitter walk (pass 1), reduced-list ranking by pointer jumping, splitter walk (pass 2, emit)
+//           -> splitter walk recording every segment's symbols, reduced-list ranking by pointer jumping,
+//              coalesced placement of the recorded segments
 // The reference follows ONE cycle at a time (n dependent loads).  Here every G-th index is a
-// splitter; a lane walks from its splitter to the next one, so ~n/G walks run concurrently.
-// Cycles that contain no splitter are found from the visited marks and resolved separately.
+// splitter; a lane walks from its splitter to the next one, so ~n/G walks run concurrently, and LF is
+// chased exactly once.  Cycles that contain no splitter are found from the visited marks and resolved separately.
 #include "internal.h"
 #include "device_utils.h"
 #include "scan_templ.h"
@@ -96,49 +97,11 @@ __global__ __launch_bounds__(LF_THREADS) void lf_rank_kernel(const u8 *__restric
 }
 
 // ------------------------------------------------------------------------------------
-// splitter walks
+// splitter walk (the only pass that chases LF)
 // ------------------------------------------------------------------------------------
-// Lanes pull splitter ids from a shared counter until none are left; every lane's walk ends
-// at the next splitter (LF is a permutation), so every wave drains.
-__global__ __launch_bounds__(256) void walk_mark_kernel(u32 *__restrict__ LF, u64 s, int g,
-                                                        u32 *__restrict__ nxt, u32 *__restrict__ seglen,
-                                                        u32 *__restrict__ segmin, u32 *__restrict__ segminoff,
-                                                        unsigned long long *__restrict__ ticket)
-{
-    const u32 gmask = (1u << g) - 1u;
-    bool have = false, done = false;
-    u64 my = 0;
-    u32 x = 0, len = 0, mn = 0, mnoff = 0;
-    for (;;) {
-        const u64 need = __ballot(!have && !done);
-        if (need) {
-            const int leader = __ffsll((unsigned long long)need) - 1;
-            unsigned long long basev = 0;
-            if (lane_id() == leader) basev = atomicAdd(ticket, (unsigned long long)__popcll(need));
-            basev = shfl_t((u64)basev, leader);
-            if (!have && !done) {
-                my = basev + (u64)__popcll(need & lanemask_lt());
-                if (my < s) { have = true; x = (u32)(my << g); len = 0; mn = x; mnoff = 0; }
-                else done = true;          // work exhausted: this lane never asks again
-            }
-        }
-        if (__ballot(have) == 0) break;
-        if (have) {
-            const u32 y = LF[x];
-            LF[x] = y | LF_TOP;
-            len++;
-            x = y;
-            if ((x & gmask) == 0) {
-                nxt[my] = x >> g; seglen[my] = len; segmin[my] = mn; segminoff[my] = mnoff;
-                have = false;
-            } else if (x < mn) { mn = x; mnoff = len; }
-        }
-    }
-}
-
 __device__ __forceinline__ u32 symbol_of(const u32 *Ctab, u32 y)
 {
-    // largest c with Ctab[c] <= y  (Ctab[256] = n)
+    // B[x] is the symbol whose C-range holds LF[x]: largest c with Ctab[c] <= y  (Ctab[256] = n)
     u32 lo = 0, hi = 255;
 #pragma unroll
     for (int it = 0; it < 8; it++) {
@@ -148,10 +111,21 @@ __device__ __forceinline__ u32 symbol_of(const u32 *Ctab, u32 y)
     return lo;
 }
 
-__global__ __launch_bounds__(256) void walk_emit_kernel(const u32 *__restrict__ LF, u64 s, int g,
-                                                        const u32 *__restrict__ opos, const u32 *__restrict__ wrap_at,
-                                                        const u32 *__restrict__ cyc_len, const u32 *__restrict__ Cg,
-                                                        u8 *__restrict__ out, unsigned long long *__restrict__ ticket)
+// A lane walks LF from its splitter to the next one.  Along the way it marks the entries it visits (top
+// bit of LF), keeps the smallest index seen, and records the symbols it passes -- B[x] read off LF[x] -- into
+// its node's slot of `seg`, 4 at a time.  A walk that reaches `slot` steps without meeting a splitter closes its
+// node there and continues as a fresh virtual node (ids >= s, handed out by an atomic counter), so no segment
+// outgrows its slot.  A wave pulls batches of splitter ids from a shared counter and hands them to its lanes as
+// they finish (one atomic per WALK_BATCH walks); every walk ends at the next splitter (LF is a permutation) and
+// a lane that finds the counter exhausted stops asking, so every wave drains.
+#define WALK_BATCH 128
+__global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, u64 s, u64 node_cap, int g, u32 slot,
+                                                          const u32 *__restrict__ Cg, u8 *__restrict__ seg,
+                                                          u32 *__restrict__ nxt, u32 *__restrict__ seglen,
+                                                          u32 *__restrict__ segmin, u32 *__restrict__ segminoff,
+                                                          unsigned long long *__restrict__ ticket,
+                                                          unsigned long long *__restrict__ vcount,
+                                                          unsigned long long *__restrict__ overflow)
 {
     __shared__ u32 Ctab[257];
     for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
@@ -159,30 +133,72 @@ __global__ __launch_bounds__(256) void walk_emit_kernel(const u32 *__restrict__ 
     const u32 gmask = (1u << g) - 1u;
     bool have = false, done = false;
     u64 my = 0;
-    u32 x = 0, i = 0, pos = 0, wr = 0, L = 0;
+    u32 x = 0, len = 0, mn = 0, mnoff = 0, symbuf = 0;
+    u64 bnext = 0, bend = 0;            // the wave's current batch of splitter ids (wave-uniform)
+    bool exhausted = false;
     for (;;) {
         const u64 need = __ballot(!have && !done);
         if (need) {
-            const int leader = __ffsll((unsigned long long)need) - 1;
-            unsigned long long basev = 0;
-            if (lane_id() == leader) basev = atomicAdd(ticket, (unsigned long long)__popcll(need));
-            basev = shfl_t((u64)basev, leader);
-            if (!have && !done) {
-                my = basev + (u64)__popcll(need & lanemask_lt());
-                if (my < s) { have = true; x = (u32)(my << g); i = 0; pos = opos[my]; wr = wrap_at[my]; L = cyc_len[my]; }
-                else done = true;
+            if (bnext == bend && !exhausted) {
+                const int leader = __ffsll((unsigned long long)need) - 1;
+                unsigned long long basev = 0;
+                if (lane_id() == leader) basev = atomicAdd(ticket, (unsigned long long)WALK_BATCH);
+                basev = shfl_t((u64)basev, leader);
+                bnext = basev;
+                bend = basev + WALK_BATCH < s ? basev + WALK_BATCH : s;
+                if (basev >= s) { exhausted = true; bnext = bend = 0; }
             }
+            if (!have && !done) {
+                const u64 id = bnext + (u64)__popcll(need & lanemask_lt());
+                if (id < bend) { have = true; my = id; x = (u32)(my << g); len = 0; mn = x; mnoff = 0; symbuf = 0; }
+                else if (exhausted) done = true;      // no work left anywhere: this lane never asks again
+            }
+            const u64 taken = bnext + (u64)__popcll(need);
+            bnext = taken < bend ? taken : bend;
         }
-        if (__ballot(have) == 0) break;
+        if (__ballot(have || !done) == 0) break;     // every lane has seen the counter run dry
         if (have) {
-            const u32 y = LF[x] & LF_MASK;
-            if (i == wr) pos += L;            // passed the cycle's smallest element: wrap to the cycle's end
-            out[pos] = (u8)symbol_of(Ctab, y);
-            pos--; i++;
+            const u32 y = LF[x];
+            LF[x] = y | LF_TOP;
+            symbuf |= symbol_of(Ctab, y) << (8 * (len & 3u));
+            if ((len & 3u) == 3u) {
+                *(u32 *)(seg + my * slot + (len & ~3u)) = symbuf;
+                symbuf = 0;
+            }
+            len++;
             x = y;
-            if ((x & gmask) == 0) have = false;
+            const bool at_splitter = (x & gmask) == 0;
+            if (at_splitter || len == slot) {
+                if (len & 3u) *(u32 *)(seg + my * slot + (len & ~3u)) = symbuf;     // slot is a multiple of 4
+                u64 next_node;
+                if (at_splitter) {
+                    next_node = x >> g;
+                    have = false;
+                } else {
+                    next_node = s + atomicAdd(vcount, 1ull);
+                    if (next_node >= node_cap) { atomicAdd(overflow, 1ull); next_node = node_cap - 1; }
+                }
+                nxt[my] = (u32)next_node; seglen[my] = len; segmin[my] = mn; segminoff[my] = mnoff;
+                if (!at_splitter) { my = next_node; len = 0; mn = x; mnoff = 0; symbuf = 0; }
+            } else if (x < mn) { mn = x; mnoff = len; }
         }
     }
+}
+
+// out[end_c - t] = B[LF^t(min_c)] (unbwts.c:73-82): node v's recorded symbols go to out[opos - i], wrapping to the
+// cycle's end once the walk passes the cycle's smallest element.  tpn threads share a node; both sides coalesce.
+__global__ __launch_bounds__(256) void place_segments_kernel(const u8 *__restrict__ seg, u64 nodes, u32 slot, int tpn_log2,
+                                                             const u32 *__restrict__ seglen, const u32 *__restrict__ opos,
+                                                             const u32 *__restrict__ wrap_at, const u32 *__restrict__ cyc_len,
+                                                             u8 *__restrict__ out)
+{
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 v = gid >> tpn_log2;
+    if (v >= nodes) return;
+    const u32 sub = (u32)(gid & ((1ull << tpn_log2) - 1ull)), tpn = 1u << tpn_log2;
+    const u32 len = seglen[v], o = opos[v], wr = wrap_at[v], L = cyc_len[v];
+    const u8 *src = seg + v * slot;
+    for (u32 i = sub; i < len; i += tpn) out[i >= wr ? o - i + L : o - i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -315,9 +331,9 @@ __global__ __launch_bounds__(256) void scatter_u32_kernel(const u32 *__restrict_
 static int splitter_log2(u64 n)
 {
     int bl = 0; for (u64 x = n; x; x >>= 1) bl++;
-    int g = bl - 20;
+    int g = bl - 21;
     if (g < 4) g = 4;
-    if (g > 10) g = 10;
+    if (g > 9) g = 9;
     const char *env = getenv("BWTS_SPLIT_LOG2");
     if (env) { int v = atoi(env); if (v >= 0 && v <= 20) g = v; }
     return g;
@@ -342,16 +358,20 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     const u64 s = (n + G - 1) / G;
     const u64 tiles = (n + LF_TILE - 1) / LF_TILE;
 
-    const size_t s4 = align_up(s * 4, 256);
+    // a segment longer than `slot` steps is cut into virtual nodes; room for s/8 of them (natural data needs ~2 %)
+    const u32 slot = (u32)(4 * G);
+    const u64 node_cap = g == 0 ? s : s + s / 8 + 1024;
+    const size_t s4 = align_up(node_cap * 4, 256);
     BWTS_TRY(arena_reserve(ctx, align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 24 * s4 +
-                                    align_up(s * sizeof(CycleRec), 256) + (1 << 16)));
+                                    align_up(node_cap * sizeof(CycleRec), 256) + align_up(node_cap * slot, 256) + (1 << 16)));
     u32 *LF = arena_array<u32>(ctx, n);
     u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
     void *scan_temp = arena_alloc(ctx, scan_temp_bytes(n));
     u32 *node[20];
-    for (int i = 0; i < 20; i++) node[i] = arena_array<u32>(ctx, s);
-    CycleRec *d_recs = (CycleRec *)arena_alloc(ctx, s * sizeof(CycleRec));
-    if (!LF || !tile_hist || !scan_temp || !node[19] || !d_recs) return BWTS_E_NOMEM;
+    for (int i = 0; i < 20; i++) node[i] = arena_array<u32>(ctx, node_cap);
+    CycleRec *d_recs = (CycleRec *)arena_alloc(ctx, node_cap * sizeof(CycleRec));
+    u8 *seg = arena_array<u8>(ctx, node_cap * slot);
+    if (!LF || !tile_hist || !scan_temp || !node[19] || !d_recs || !seg) return BWTS_E_NOMEM;
     u32 *nxt = node[0], *seglen = node[1], *segmin = node[2], *segoff = node[3];
     u32 *d_opos = node[4], *d_wrap = node[5], *d_clen = node[6];
     u32 *lead[2] = {node[7], node[8]}, *cmin[2] = {node[9], node[10]}, *hop[2] = {node[11], node[12]};
@@ -380,16 +400,21 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         HIPC(hipGetLastError());
     }
 
-    // pass 1: walk + mark
+    // the walk: marks, segment symbols, reduced list
     unsigned long long *ticket = (unsigned long long *)(ctx->d_small + SMI_COUNTERS);
     HIPC(hipMemsetAsync(ticket, 0, 8 * sizeof(u64), ctx->stream));
     const u64 walkers = s < 524288 ? s : 524288;
     const unsigned wblocks = (unsigned)((walkers + 255) / 256);
     {
-        SpanGuard sg(ctx, BWTS_K_WALK, n, 4 * n);
-        walk_mark_kernel<<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, s, g, nxt, seglen, segmin, segoff, ticket);
+        SpanGuard sg(ctx, BWTS_K_WALK, n, 6 * n);
+        walk_record_kernel<<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, s, node_cap, g, slot, dC, seg, nxt, seglen, segmin, segoff,
+                                                                        ticket, ticket + 3, ticket + 4);
         HIPC(hipGetLastError());
     }
+    // virtual nodes join the reduced list: its size is only known now
+    BWTS_TRY(read_small(ctx, SMI_COUNTERS, 8));
+    if (ctx->h_small[SMI_COUNTERS + 4]) { *retry = true; return BWTS_OK; }   // node pool exhausted (adversarial LF): plain pointer jumping
+    const u64 s_all = s + ctx->h_small[SMI_COUNTERS + 3];
 
     // elements in splitter-free cycles
     char *ub = nullptr;
@@ -403,22 +428,22 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     }
 
     // reduced-list ranking on the device
-    const int R = [&] { int b = 0; for (u64 x = s; x; x >>= 1) b++; return b; }();   // 2^R > s >= any cycle's node count
+    const int R = [&] { int b = 0; for (u64 x = s_all; x; x >>= 1) b++; return b; }();   // 2^R > s >= any cycle's node count
     int cur = 0;
     {
-        SpanGuard sg(ctx, BWTS_K_LISTRANK, s, 0);
-        const int gb = grid1(s);
-        lr_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, nxt, segmin, lead[0], cmin[0], hop[0]);
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, s_all, 0);
+        const int gb = grid1(s_all);
+        lr_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nxt, segmin, lead[0], cmin[0], hop[0]);
         for (int r = 0; r < R; r++, cur ^= 1)
-            lr_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, lead[cur], cmin[cur], hop[cur], lead[cur ^ 1], cmin[cur ^ 1], hop[cur ^ 1]);
+            lr_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, lead[cur], cmin[cur], hop[cur], lead[cur ^ 1], cmin[cur ^ 1], hop[cur ^ 1]);
         u32 *leadf = lead[cur], *cminf = cmin[cur];
         int sc = 0;
-        lr_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, nxt, seglen, leadf, sum[0], hop[0]);
+        lr_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nxt, seglen, leadf, sum[0], hop[0]);
         int hc = 0;
         u32 *hopb[2] = {hop[0], hop[1]};
         for (int r = 0; r < R; r++, sc ^= 1, hc ^= 1)
-            lr_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, sum[sc], hopb[hc], sum[sc ^ 1], hopb[hc ^ 1]);
-        lr_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s, leadf, cminf, sum[sc], segmin, segoff, dist, min_dist, d_recs, ticket + 2);
+            lr_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, sum[sc], hopb[hc], sum[sc ^ 1], hopb[hc ^ 1]);
+        lr_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, leadf, cminf, sum[sc], segmin, segoff, dist, min_dist, d_recs, ticket + 2);
         HIPC(hipGetLastError());
         // keep the final buffers' identities for the placement kernel
         lead[0] = leadf; sum[0] = sum[sc];
@@ -427,7 +452,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
     const u64 kc = ctx->h_small[SMI_COUNTERS + 2];
     ctx->tm.unvisited = nu;
-    if (kc == 0 || kc > s) return BWTS_E_INTERNAL;
+    if (kc == 0 || kc > s_all) return BWTS_E_INTERNAL;
     if (nu > UNV_CAP) { *retry = true; return BWTS_OK; }   // Theta(n) elements in tiny cycles
 
     // host: order the cycles by smallest element (unbwts.c:62-77); splitter-free cycles join here
@@ -489,17 +514,21 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     HIPC(hipMemcpyAsync(tmp_idx, h_lidx.data(), kc * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPC(hipMemcpyAsync(tmp_val, h_lend.data(), kc * 4, hipMemcpyHostToDevice, ctx->stream));
     {
-        SpanGuard sg(ctx, BWTS_K_LISTRANK, s, 0);
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, s_all, 0);
         scatter_u32_kernel<<<dim3(grid1(kc)), dim3(256), 0, ctx->stream>>>(tmp_idx, tmp_val, kc, end_by_leader);
-        lr_place_kernel<<<dim3(grid1(s)), dim3(256), 0, ctx->stream>>>(s, lead[0], sum[0], dist, min_dist, end_by_leader, d_opos, d_wrap, d_clen);
+        lr_place_kernel<<<dim3(grid1(s_all)), dim3(256), 0, ctx->stream>>>(s_all, lead[0], sum[0], dist, min_dist, end_by_leader, d_opos, d_wrap, d_clen);
         HIPC(hipGetLastError());
     }
 
-    // pass 2: walk + emit (unbwts.c:73-82)
-    HIPC(hipMemsetAsync(ticket, 0, sizeof(u64), ctx->stream));
+    // the recorded segments go to their places in the text (unbwts.c:73-82)
     {
-        SpanGuard sg(ctx, BWTS_K_WALK_EMIT, n, 6 * n);
-        walk_emit_kernel<<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, s, g, d_opos, d_wrap, d_clen, dC, d_out, ticket);
+        SpanGuard sg(ctx, BWTS_K_WALK_EMIT, n, 2 * n);
+        int tpn_log2 = g + 2 - 4;                       // ~16 symbols per thread at the expected segment length
+        if (tpn_log2 < 0) tpn_log2 = 0;
+        if (tpn_log2 > 8) tpn_log2 = 8;
+        const u64 threads = s_all << tpn_log2;
+        place_segments_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(seg, s_all, slot, tpn_log2, seglen,
+                                                                                                      d_opos, d_wrap, d_clen, d_out);
         HIPC(hipGetLastError());
     }
     // elements of splitter-free cycles
