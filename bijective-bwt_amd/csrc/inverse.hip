@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
     const u32 gmask = (1u << g) - 1u;
     bool have = false, done = false;
     u64 my = 0;
-    u32 x = 0, len = 0, mn = 0, mnoff = 0, symbuf = 0;
+    u32 x = 0, len = 0, mn = 0, mnoff = 0;
+    u32 sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;     // 16 recorded symbols waiting for one 16-byte store
     u64 bnext = 0, bend = 0;            // the wave's current batch of splitter ids (wave-uniform)
     bool exhausted = false;
     for (;;) {
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
             }
             if (!have && !done) {
                 const u64 id = bnext + (u64)__popcll(need & lanemask_lt());
-                if (id < bend) { have = true; my = id; x = (u32)(my << g); len = 0; mn = x; mnoff = 0; symbuf = 0; }
+                if (id < bend) { have = true; my = id; x = (u32)(my << g); len = 0; mn = x; mnoff = 0; sb0 = sb1 = sb2 = sb3 = 0; }
                 else if (exhausted) done = true;      // no work left anywhere: this lane never asks again
             }
             const u64 taken = bnext + (u64)__popcll(need);
@@ -160,16 +161,20 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
         if (have) {
             const u32 y = LF[x];
             LF[x] = y | LF_TOP;
-            symbuf |= symbol_of(Ctab, y) << (8 * (len & 3u));
-            if ((len & 3u) == 3u) {
-                *(u32 *)(seg + my * slot + (len & ~3u)) = symbuf;
-                symbuf = 0;
+            {
+                const u32 sh = symbol_of(Ctab, y) << (8 * (len & 3u));
+                const u32 w = (len >> 2) & 3u;
+                sb0 |= w == 0 ? sh : 0u; sb1 |= w == 1 ? sh : 0u; sb2 |= w == 2 ? sh : 0u; sb3 |= w == 3 ? sh : 0u;
+            }
+            if ((len & 15u) == 15u) {
+                *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);
+                sb0 = sb1 = sb2 = sb3 = 0;
             }
             len++;
             x = y;
             const bool at_splitter = (x & gmask) == 0;
             if (at_splitter || len == slot) {
-                if (len & 3u) *(u32 *)(seg + my * slot + (len & ~3u)) = symbuf;     // slot is a multiple of 4
+                if (len & 15u) *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);   // slot is a multiple of 16
                 u64 next_node;
                 if (at_splitter) {
                     next_node = x >> g;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                     if (next_node >= node_cap) { atomicAdd(overflow, 1ull); next_node = node_cap - 1; }
                 }
                 nxt[my] = (u32)next_node; seglen[my] = len; segmin[my] = mn; segminoff[my] = mnoff;
-                if (!at_splitter) { my = next_node; len = 0; mn = x; mnoff = 0; symbuf = 0; }
+                if (!at_splitter) { my = next_node; len = 0; mn = x; mnoff = 0; sb0 = sb1 = sb2 = sb3 = 0; }
             } else if (x < mn) { mn = x; mnoff = len; }
         }
     }
@@ -359,7 +364,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     const u64 tiles = (n + LF_TILE - 1) / LF_TILE;
 
     // a segment longer than `slot` steps is cut into virtual nodes; room for s/8 of them (natural data needs ~2 %)
-    const u32 slot = (u32)(4 * G);
+    const u32 slot = (u32)(4 * G < 16 ? 16 : 4 * G);
     const u64 node_cap = g == 0 ? s : s + s / 8 + 1024;
     const size_t s4 = align_up(node_cap * 4, 256);
     BWTS_TRY(arena_reserve(ctx, align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 24 * s4 +
