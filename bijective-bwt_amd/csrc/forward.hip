@@ -371,6 +371,14 @@ struct SortSpace {
     u32 *rank;        // n
     u32 *tile_hist;
     void *scan_temp;
+    // emission riding on round 0 (cyclic sort only): P[p] = T[cprev(p)] travels with the pairs and the last
+    // pass writes it straight into the output; null = gather after the sort instead
+    const u8 *carry_src = nullptr;
+    u8 *carry_buf[2] = {nullptr, nullptr};
+    u8 *carry_out = nullptr;
+    // the round-0 tie list (slots), for patching the carried bytes of elements that later rounds reorder
+    const u32 *tie_slots = nullptr;
+    u64 tie_count = 0;
 };
 
 static size_t sort_space_bytes(u64 n)
@@ -418,6 +426,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     plan.keys[0] = sp.keys[0]; plan.keys[1] = sp.keys[1];
     plan.vals[0] = sp.vals[0]; plan.vals[1] = sp.vals[1];
     plan.tile_hist = sp.tile_hist; plan.scan_temp = sp.scan_temp;
+    plan.sym_src = sp.carry_src; plan.sym_buf[0] = sp.carry_buf[0]; plan.sym_buf[1] = sp.carry_buf[1]; plan.sym_final = sp.carry_out;
     int res = 0;
     BWTS_TRY(radix_sort_pairs(ctx, plan, n, al.key_bits, &res));
     u64 *K0 = sp.keys[res];
@@ -438,6 +447,8 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
     u64 a = ctx->h_small[CNT_ACTIVE];
     *active0_out = a;
+    sp.tie_slots = cur.slot;        // stays untouched by the later rounds
+    sp.tie_count = a;
     u32 rounds = 1;
     bool rank_valid = false;
     ActiveList none{nullptr, nullptr, nullptr};
@@ -790,10 +801,18 @@ __global__ __launch_bounds__(256) void emit_kernel(const u32 *__restrict__ SA, c
     }
 }
 
+// bytes of elements that the later rounds moved: out[slot] = P[sa[slot]]
+__global__ __launch_bounds__(256) void patch_ties_kernel(const u32 *__restrict__ slots, u64 a, const u32 *__restrict__ SA,
+                                                         const u8 *__restrict__ P, u8 *__restrict__ out)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < a) { const u32 r = slots[i]; out[r] = P[SA[r]]; }
+}
+
 size_t forward_arena_bytes(u64 n)
 {
-    // candidate buffers + sort space + factor list (general path: up to n entries) + P
-    return 8 * align_up(LYN_CAND_CAP * 8, 256) + sort_space_bytes(n) + align_up(n * 4, 256) + align_up(n, 256) + (1 << 16);
+    // candidate buffers + sort space + factor list (general path: up to n entries) + P + two carry buffers
+    return 8 * align_up(LYN_CAND_CAP * 8, 256) + sort_space_bytes(n) + align_up(n * 4, 256) + 3 * align_up(n, 256) + (1 << 16);
 }
 
 int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
@@ -814,6 +833,26 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     ctx->tm.key_symbols = (u32)al.msym;
     ctx->tm.key_bits = (u32)al.key_bits;
 
+    // P[p] = T[cprev(p)] (mk_bwts_sa.c:172-188): a factor's head takes the factor's last byte
+    u8 *P = arena_array<u8>(ctx, n);
+    if (!P) return BWTS_E_NOMEM;
+    {
+        SpanGuard g(ctx, BWTS_K_OTHER, n, 2 * n);
+        u64 blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+        prevsym_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(d_in, n, P);
+        prevsym_fix_kernel<<<dim3((unsigned)((k + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_in, n, d_fstart, k, P);
+        HIPC(hipGetLastError());
+    }
+    const char *emit_env = getenv("BWTS_EMIT");      // carry (default) | gather
+    const bool carry = radix_supports_sym() && !(emit_env && !strcmp(emit_env, "gather"));
+    if (carry) {
+        sp.carry_src = P;
+        sp.carry_buf[0] = arena_array<u8>(ctx, n);
+        sp.carry_buf[1] = arena_array<u8>(ctx, n);
+        sp.carry_out = d_out;
+        if (!sp.carry_buf[0] || !sp.carry_buf[1]) return BWTS_E_NOMEM;
+    }
+
     // 2. cyclic sort
     u32 *SA = nullptr;
     u32 rounds = 0;
@@ -822,16 +861,13 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     ctx->tm.rounds = rounds;
     ctx->tm.active_after_round0 = active0;
 
-    // 3. emission
-    u8 *P = arena_array<u8>(ctx, n);
-    if (!P) return BWTS_E_NOMEM;
-    {
-        SpanGuard g(ctx, BWTS_K_OTHER, n, 2 * n);
-        u64 blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
-        prevsym_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(d_in, n, P);
-        prevsym_fix_kernel<<<dim3((unsigned)((k + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_in, n, d_fstart, k, P);
-    }
-    {
+    // 3. emission: either it rode on the sort (only the tied elements are patched), or a gather
+    if (carry) {
+        if (active0) {
+            SpanGuard g(ctx, BWTS_K_EMIT, active0, 6 * active0);
+            patch_ties_kernel<<<dim3((unsigned)((active0 + 255) / 256)), dim3(256), 0, ctx->stream>>>(sp.tie_slots, active0, SA, P, d_out);
+        }
+    } else {
         SpanGuard g(ctx, BWTS_K_EMIT, n, 6 * n);
         const u64 octs = (n + 7) / 8;
         emit_kernel<<<dim3((unsigned)((octs + 255) / 256)), dim3(256), 0, ctx->stream>>>(SA, P, n, d_out);

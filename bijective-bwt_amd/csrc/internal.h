@@ -95,7 +95,12 @@ struct SortPlan {
     u32  *vals[2];
     u32  *tile_hist;      // 256 * tiles(m)
     void *scan_temp;
+    // optional third stream: one byte per element travels with the pair (all three may be null)
+    const u8 *sym_src = nullptr;     // byte of element i before the first pass
+    u8 *sym_buf[2] = {nullptr, nullptr};
+    u8 *sym_final = nullptr;         // where the last pass leaves the bytes
 };
+bool radix_supports_sym(void);       // the byte stream is compiled for the default tile shape only
 u64    radix_tiles(u64 m);
 size_t radix_tile_hist_bytes(u64 m);
 // Sorts on key bits [0, key_bits); returns in *result_buf which of keys[]/vals[] holds the output.

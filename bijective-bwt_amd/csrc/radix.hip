@@ -231,22 +231,26 @@ __global__ __launch_bounds__(RX_THREADS) void radix_scatter_kernel(const u64 *__
     }
 }
 
-// Variant 1: the LDS tile holds the keys first and is then reused for the values, and the
-// per-wave digit counters are 16-bit: 8 B of LDS per element instead of 12, so two 8192-element
-// tiles fit a CU and one tile's loads overlap the other's ranking.
-template <int RX_THREADS, int RX_ITEMS, int MINW>
+// Variant 1: the LDS tile holds the keys first and is then reused for the values (and, optionally, a third
+// one-byte stream), the per-wave digit counters are 16-bit and each slot's digit is kept in a byte table, so
+// the destination of a slot is re-derived instead of living in a register: 9 B of LDS per element instead
+// of 12, two 8192-element tiles fit a CU and one tile's loads overlap the other's ranking.
+template <int RX_THREADS, int RX_ITEMS, int MINW, bool HAS_SYM>
 __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
                                                                      u64 *__restrict__ kout, u32 *__restrict__ vout,
-                                                                     const u32 *__restrict__ tile_off, u64 m, int shift)
+                                                                     const u32 *__restrict__ tile_off, u64 m, int shift,
+                                                                     const u8 *__restrict__ sin, u8 *__restrict__ sout)
 {
     constexpr int RX_WAVES = RX_THREADS / 64;
     constexpr int RX_TILE = RX_THREADS * RX_ITEMS;
+    static_assert(RX_TILE <= 65536 && RX_ITEMS % 2 == 0, "positions are packed as 16-bit pairs");
     extern __shared__ __attribute__((aligned(16))) char rx_smem[];
-    u64 *stage = (u64 *)rx_smem;                                   // RX_TILE keys, later RX_TILE values
+    u64 *stage = (u64 *)rx_smem;                                   // RX_TILE keys, later values, later bytes
     u32 *dbase = (u32 *)(stage + RX_TILE);                         // 256
     u32 *gbase = dbase + 256;                                      // 256
     u32 *scan_sm = gbase + 256;                                    // RX_WAVES (padded to 16)
     u16 (*whist)[256] = (u16 (*)[256])(scan_sm + 16);              // RX_WAVES x 256
+    u8 *sdig = (u8 *)(whist + RX_WAVES);                           // RX_TILE: digit of the element in slot s
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const u64 tile = rx_tile_of_block((m + RX_TILE - 1) / RX_TILE);
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
     for (int i = tid; i < RX_WAVES * 128; i += RX_THREADS) ((u32 *)whist)[i] = 0;
 
     u64 key[RX_ITEMS];
-    u32 pos[RX_ITEMS];
+    u32 posp[RX_ITEMS / 2];                                        // two 16-bit tile positions per register
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const u64 i = wave_base + (u64)j * 64 + lane;
@@ -275,17 +279,10 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
         const u32 before = (u32)__popcll(peers & lanemask_lt());
         const u32 cnt = (u32)__popcll(peers);
         const u32 prev = whist[w][d];
-        pos[j] = prev + before;
+        if (j & 1) posp[j >> 1] |= (prev + before) << 16; else posp[j >> 1] = prev + before;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (valid && before == 0) whist[w][d] = (u16)(prev + cnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    // values are only needed after the keys have left: start their loads now
-    u32 val[RX_ITEMS];
-#pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const u64 i = wave_base + (u64)j * 64 + lane;
-        val[j] = i < m ? vin[i] : 0u;
     }
     __syncthreads();
     {
@@ -311,18 +308,26 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
     for (int j = 0; j < RX_ITEMS; j++) {
         const bool valid = wave_base + (u64)j * 64 + lane < m;
         const u32 d = (u32)(key[j] >> shift) & 255u;
-        pos[j] += dbase[d] + whist[w][d];
-        if (valid) stage[pos[j]] = key[j];
+        const u32 p = ((j & 1) ? posp[j >> 1] >> 16 : posp[j >> 1] & 0xffffu) + dbase[d] + whist[w][d];
+        if (j & 1) posp[j >> 1] = (posp[j >> 1] & 0xffffu) | (p << 16); else posp[j >> 1] = (posp[j >> 1] & 0xffff0000u) | p;
+        if (valid) stage[p] = key[j];
+    }
+    // the keys' registers are free: the value loads overlap the key write-out
+    u32 val[RX_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const u64 i = wave_base + (u64)j * 64 + lane;
+        val[j] = i < m ? vin[i] : 0u;
     }
     __syncthreads();
-    u32 dst[RX_ITEMS];
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const u32 s = (u32)j * RX_THREADS + tid;
         if (s < tile_count) {
             const u64 k = stage[s];
-            dst[j] = gbase[(u32)(k >> shift) & 255u] + s;
-            kout[dst[j]] = k;
+            const u32 d = (u32)(k >> shift) & 255u;
+            sdig[s] = (u8)d;
+            kout[gbase[d] + s] = k;
         }
     }
     __syncthreads();
@@ -330,13 +335,42 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const bool valid = wave_base + (u64)j * 64 + lane < m;
-        if (valid) vstage[pos[j]] = val[j];
+        const u32 p = (j & 1) ? posp[j >> 1] >> 16 : posp[j >> 1] & 0xffffu;
+        if (valid) vstage[p] = val[j];
+    }
+    // the third stream's loads overlap the value write-out
+    u32 symp[(RX_ITEMS + 3) / 4];
+    if (HAS_SYM) {
+#pragma unroll
+        for (int q = 0; q < (RX_ITEMS + 3) / 4; q++) symp[q] = 0;
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) {
+            const u64 i = wave_base + (u64)j * 64 + lane;
+            const u32 b = i < m ? (u32)sin[i] : 0u;
+            symp[j >> 2] |= b << (8 * (j & 3));
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const u32 s = (u32)j * RX_THREADS + tid;
-        if (s < tile_count) vout[dst[j]] = vstage[s];
+        if (s < tile_count) vout[gbase[sdig[s]] + s] = vstage[s];
+    }
+    if (HAS_SYM) {
+        __syncthreads();
+        u8 *bstage = (u8 *)stage;
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) {
+            const bool valid = wave_base + (u64)j * 64 + lane < m;
+            const u32 p = (j & 1) ? posp[j >> 1] >> 16 : posp[j >> 1] & 0xffffu;
+            if (valid) bstage[p] = (u8)(symp[j >> 2] >> (8 * (j & 3)));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) {
+            const u32 s = (u32)j * RX_THREADS + tid;
+            if (s < tile_count) sout[gbase[sdig[s]] + s] = bstage[s];
+        }
     }
 }
 
@@ -363,17 +397,17 @@ static int launch_scatter_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32 
     return BWTS_OK;
 }
 
-template <int TH, int IT, int MINW>
+template <int TH, int IT, int MINW, bool HAS_SYM = false>
 static int launch_scatter2_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *tile_off,
-                             u64 m, int shift)
+                             u64 m, int shift, const u8 *sin = nullptr, u8 *sout = nullptr)
 {
-    constexpr size_t lds = (size_t)TH * IT * 8 + 2048 + 64 + (size_t)(TH / 64) * 512;
+    constexpr size_t lds = (size_t)TH * IT * 9 + 2048 + 64 + (size_t)(TH / 64) * 512;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPC(hipFuncSetAttribute((const void *)radix_scatter2_kernel<TH, IT, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPC(hipFuncSetAttribute((const void *)radix_scatter2_kernel<TH, IT, MINW, HAS_SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    radix_scatter2_kernel<TH, IT, MINW><<<dim3((unsigned)rx_grid(tiles)), dim3(TH), lds, ctx->stream>>>(kin, vin, kout, vout, tile_off, m, shift);
+    radix_scatter2_kernel<TH, IT, MINW, HAS_SYM><<<dim3((unsigned)rx_grid(tiles)), dim3(TH), lds, ctx->stream>>>(kin, vin, kout, vout, tile_off, m, shift, sin, sout);
     return BWTS_OK;
 }
 
@@ -435,6 +469,8 @@ int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp)
     return BWTS_OK;
 }
 
+bool radix_supports_sym(void) { return rx_config_index() == 8; }
+
 int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, int *result_buf)
 {
     int cur = 0;
@@ -456,7 +492,14 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
             SpanGuard g(ctx, BWTS_K_RADIX_SCAN, tiles * 256, tiles * 256 * 12);
             BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, plan.scan_temp));
         }
-        {
+        if (plan.sym_src) {
+            if (cfg != 8) return BWTS_E_INTERNAL;
+            const u8 *sin = p == 0 ? plan.sym_src : plan.sym_buf[(p - 1) & 1];
+            u8 *sout = p == passes - 1 ? plan.sym_final : plan.sym_buf[p & 1];
+            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 26 * m);
+            BWTS_TRY((launch_scatter2_t<512, 16, 4, true>(ctx, tiles, plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1], plan.vals[cur ^ 1],
+                                                           tile_hist, m, shift, sin, sout)));
+        } else {
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 24 * m);
             BWTS_TRY(launch_scatter(ctx, cfg, tiles, plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1], plan.vals[cur ^ 1], tile_hist, m,
                                     shift));
