@@ -153,10 +153,12 @@ __device__ __forceinline__ u64 factor_end(const u32 *__restrict__ fstart, u64 k,
 
 __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes_g,
                                                                int bits, int msym, int pad_add,
-                                                               u64 *__restrict__ keys, u32 *__restrict__ vals)
+                                                               u64 *__restrict__ keys, u32 *__restrict__ vals,
+                                                               u64 *__restrict__ tile_min /* may be null */)
 {
     __shared__ u16 sc[KB_TILE + KB_HALO];
     __shared__ u8 codes[256];
+    __shared__ u64 wmin[KB_THREADS / 64];
 
     const int tid = threadIdx.x;
     const u64 base = (u64)blockIdx.x * KB_TILE;
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
     }
     __syncthreads();
     const u32 o = (u32)tid * KB_ITEMS;
+    u64 lo = ~0ull;
     if (base + o < end) {
         u64 key = 0;
         for (int j = 0; j < msym; j++) key = (key << bits) | sc[o + j];
@@ -183,8 +186,20 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
             if (p < end) {
                 keys[p] = key;
                 vals[p] = (u32)p;
+                lo = key < lo ? key : lo;
                 key = ((key << bits) | sc[o + e + msym]) & mask;   // stays inside the loaded span / halo
             }
+        }
+    }
+    // smallest key of the tile: the Lyndon candidate search starts from these (same tile size as the scan)
+    if (tile_min) {
+        lo = wave_scan_inclusive(lo, OpMin());
+        if (lane_id() == 63) wmin[wave_id()] = lo;
+        __syncthreads();
+        if (tid == 0) {
+            u64 t = wmin[0];
+            for (int w = 1; w < KB_THREADS / 64; w++) t = wmin[w] < t ? wmin[w] : t;
+            tile_min[blockIdx.x] = t;
         }
     }
 }
@@ -309,26 +324,28 @@ __device__ __forceinline__ void group_flags(const u64 *__restrict__ K, u64 i, u6
 }
 
 struct GroupIn {
-    const u64 *K; const u32 *S; u64 a;     // S == nullptr: slot(i) = i (round 0)
-    __device__ __forceinline__ u64 operator()(u64 i) const
+    const u64 *K; const u32 *S; u64 a; int rb;     // S == nullptr: slot(i) = i (round 0)
+    __device__ __forceinline__ u64 operator()(u64 i, u32 *note) const
     {
         u64 ki; bool f0, f1, so;
-        group_flags(K, i, a, &ki, &f0, &f1, &so, -1);
+        group_flags(K, i, a, &ki, &f0, &f1, &so, rb);
+        *note = (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (so ? 4u : 0u);
         const u32 hv = f0 ? (S ? S[i] : (u32)i) : 0u;
         return ((u64)hv << 32) | (u64)((f0 && f1) ? 0u : 1u);
     }
+    __device__ __forceinline__ u64 operator()(u64 i) const { u32 note; return (*this)(i, &note); }
 };
 
 struct GroupOut {
-    const u64 *K; const u32 *S; const u32 *V; u64 a; int rb;   // rb < 0: round 0 (no older groups)
-    u32 *rank;                                                  // may be nullptr (ranks not materialised yet)
+    const u32 *S; const u32 *V; u64 a; int rb;     // rb < 0: round 0 (no older groups)
+    u32 *rank;                                      // may be nullptr (ranks not materialised yet)
     u32 *SA;
     u32 *n_idx, *n_slot, *n_head;
     u64 *cnt_active, *cnt_splits;
-    __device__ __forceinline__ void operator()(u64 i, u64 v) const
+    // note: the flags GroupIn computed for this element (same lane), so the keys are not read again
+    __device__ __forceinline__ void operator()(u64 i, u64 v, u32 note) const
     {
-        u64 ki; bool f0, f1, same_old;
-        group_flags(K, i, a, &ki, &f0, &f1, &same_old, rb);
+        const bool f0 = note & 1u, f1 = note & 2u, same_old = note & 4u;
         const bool keep = !(f0 && f1);
         const u32 head = (u32)(v >> 32);
         const u32 val = (keep || rank || S) ? V[i] : 0u;     // round 0 touches the suffix array only for tied elements
@@ -440,8 +457,8 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
     {
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
-        GroupIn in{K0, nullptr, n};
-        GroupOut out{K0, nullptr, SA, n, -1, nullptr, SA, cur.idx, cur.slot, cur.head, cnt + 0, cnt + 1};
+        GroupIn in{K0, nullptr, n, -1};
+        GroupOut out{nullptr, SA, n, -1, nullptr, SA, cur.idx, cur.slot, cur.head, cnt + 0, cnt + 1};
         BWTS_TRY((device_scan<true, u64>(ctx, n, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
     }
     BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
@@ -498,8 +515,8 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
             {
                 SpanGuard g(ctx, BWTS_K_RERANK, a, 24 * a);
-                GroupIn in{AK, cur.slot, a};
-                GroupOut out{AK, cur.slot, AV, a, rb, rank_valid ? sp.rank : nullptr, SA,
+                GroupIn in{AK, cur.slot, a, rb};
+                GroupOut out{cur.slot, AV, a, rb, rank_valid ? sp.rank : nullptr, SA,
                              sets[nxt].idx, sets[nxt].slot, sets[nxt].head, cnt + 0, cnt + 1};
                 BWTS_TRY((device_scan<true, u64>(ctx, a, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
             }
@@ -526,12 +543,14 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     return BWTS_OK;
 }
 
-static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp)
+static_assert(KB_TILE == SCAN_TILE, "keybuild0's tile minima feed the scan's final sweep");
+
+static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp, u64 *tile_min)
 {
     SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + 12 * n);
     const u64 blocks = (n + KB_TILE - 1) / KB_TILE;
     keybuild0_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(
-        d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, sp.keys[0], sp.vals[0]);
+        d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, sp.keys[0], sp.vals[0], tile_min);
     HIPC(hipGetLastError());
     return BWTS_OK;
 }
@@ -560,7 +579,7 @@ static int suffix_sort_in(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, bo
     if (n > 0xffffffffull) return BWTS_E_RANGE;
     Alphabet al;
     BWTS_TRY(set_alphabet(ctx, true, &al));
-    BWTS_TRY(launch_keybuild0(ctx, d_T, n, al, sp));
+    BWTS_TRY(launch_keybuild0(ctx, d_T, n, al, sp, nullptr));
     u64 active0 = 0;
     return doubling_sort<false>(ctx, d_T, n, al, nullptr, 0, sp, want_ranks, d_sa, rounds, &active0);
 }
@@ -634,6 +653,11 @@ struct CandOut {
     }
 };
 
+struct TileMayHoldCandidate {
+    const u64 *tile_min;
+    __device__ __forceinline__ bool operator()(u64 t, u64 min_before) const { return tile_min[t] <= min_before; }
+};
+
 // one workgroup walks the position-sorted candidates; exact suffix comparison is block-wide
 __global__ __launch_bounds__(256) void lyndon_resolve_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ cand, u64 cnt,
                                                              u32 *__restrict__ fstart, u64 *__restrict__ out_k, u64 *__restrict__ out_ovf,
@@ -679,17 +703,23 @@ __global__ __launch_bounds__(256) void lyndon_resolve_kernel(const u8 *__restric
 }
 
 // returns BWTS_OK with *done = false when the input needs the general path
-static int lyndon_fast(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp, u64 *cand[2], u32 *cvals[2],
-                       u32 *fstart, u64 *k_out, bool *done)
+static int lyndon_fast(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp, const u64 *tile_min, u64 *cand[2],
+                       u32 *cvals[2], u32 *fstart, u64 *k_out, bool *done)
 {
     *done = false;
     u64 *cnt = ctx->d_small + SM_COUNTERS;
     HIPC(hipMemsetAsync(cnt + 4, 0, 4 * sizeof(u64), ctx->stream));
     {
-        SpanGuard g(ctx, BWTS_K_LYNDON, n, 8 * n);
+        // keybuild0 left every tile's smallest key in tile_min; after the exclusive min-scan of those, a tile can
+        // hold a candidate only if its own minimum does not exceed the minimum of everything before it
+        SpanGuard g(ctx, BWTS_K_LYNDON, n, 0);
+        const u64 tiles = scan_tiles(n);
+        HIPC(hipMemcpyAsync(sp.scan_temp, tile_min, tiles * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+        BWTS_TRY((device_scan_partials<u64, OpMin>(ctx, tiles, OpMin(), ~0ull, sp.scan_temp)));
         KeyIn in{sp.keys[0]};
         CandOut out{sp.keys[0], n, al.msym, cand[0], LYN_CAND_CAP, ctx->d_small + CNT_CAND};
-        BWTS_TRY((device_scan<false, u64>(ctx, n, in, out, OpMin(), ~0ull, sp.scan_temp)));
+        TileMayHoldCandidate filter{tile_min};
+        BWTS_TRY((device_scan_final<false, u64>(ctx, n, in, out, OpMin(), ~0ull, sp.scan_temp, filter)));
     }
     BWTS_TRY(read_small(ctx, CNT_CAND, 1));
     const u64 cnt_c = ctx->h_small[CNT_CAND];
@@ -743,16 +773,18 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
     bool done = false;
     *lyndon_rounds = 0;
     if (mode != 2) {
+        u64 *tile_min = arena_array<u64>(ctx, scan_tiles(n) + 1);
+        if (!tile_min) return BWTS_E_NOMEM;
         BWTS_TRY(set_alphabet(ctx, false, al));
-        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp));
-        BWTS_TRY(lyndon_fast(ctx, d_T, n, *al, sp, cand, cvals, fast_starts, k_out, &done));
+        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, tile_min));
+        BWTS_TRY(lyndon_fast(ctx, d_T, n, *al, sp, tile_min, cand, cvals, fast_starts, k_out, &done));
         if (done) *d_fstart = fast_starts;
         else if (mode == 1) return BWTS_E_INTERNAL;
     }
     if (!done) {
         BWTS_TRY(lyndon_general(ctx, d_T, n, sp, d_fstart, k_out, lyndon_rounds));
         BWTS_TRY(set_alphabet(ctx, false, al));
-        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp));
+        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, nullptr));
     }
     // wrap the keys of positions near their factor's end
     if (al->msym > 1) {
@@ -812,7 +844,8 @@ __global__ __launch_bounds__(256) void patch_ties_kernel(const u32 *__restrict__
 size_t forward_arena_bytes(u64 n)
 {
     // candidate buffers + sort space + factor list (general path: up to n entries) + P + two carry buffers
-    return 8 * align_up(LYN_CAND_CAP * 8, 256) + sort_space_bytes(n) + align_up(n * 4, 256) + 3 * align_up(n, 256) + (1 << 16);
+    return 8 * align_up(LYN_CAND_CAP * 8, 256) + sort_space_bytes(n) + align_up(n * 4, 256) + 3 * align_up(n, 256) + align_up(n / 256 + 64, 256) +
+           (1 << 16);
 }
 
 int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)

@@ -7,6 +7,7 @@
 #define SCAN_THREADS 256
 #define SCAN_ITEMS   8
 #define SCAN_TILE    (SCAN_THREADS * SCAN_ITEMS)
+#define SCAN_SINGLE_BLOCK_MAX 8192ull     // partial counts up to this are scanned by one workgroup
 
 static inline u64 scan_tiles(u64 n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 
@@ -49,22 +50,39 @@ __global__ __launch_bounds__(1024) void scan_partials_kernel(u64 count, Op op, T
     }
 }
 
+// functors either take (i) / (i, value) or, to pass a note from load to store, (i, u32*) / (i, value, u32)
+template <int N> struct scan_rank : scan_rank<N - 1> {};
+template <> struct scan_rank<0> {};
+template <typename F> __device__ __forceinline__ auto scan_call_in_(const F &f, u64 i, u32 *note, scan_rank<1>) -> decltype(f(i, note)) { return f(i, note); }
+template <typename F> __device__ __forceinline__ auto scan_call_in_(const F &f, u64 i, u32 *, scan_rank<0>) -> decltype(f(i)) { return f(i); }
+template <typename F, typename T> __device__ __forceinline__ auto scan_call_out_(const F &f, u64 i, T v, u32 note, scan_rank<1>) -> decltype(f(i, v, note)) { return f(i, v, note); }
+template <typename F, typename T> __device__ __forceinline__ auto scan_call_out_(const F &f, u64 i, T v, u32, scan_rank<0>) -> decltype(f(i, v)) { return f(i, v); }
+#define scan_call_in(f, i, note) scan_call_in_(f, i, note, scan_rank<1>())
+#define scan_call_out(f, i, v, note) scan_call_out_(f, i, v, note, scan_rank<1>())
+
 // LDS slot of tile element e: one pad slot per 8 keeps the blocked (8 per thread) accesses
 // spread over the banks
 #define SCAN_SLOT(e) ((e) + ((e) >> 3))
 
-template <typename T, typename Op, typename InF, typename OutF, bool INCLUSIVE>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(u64 n, InF in, OutF out, Op op, T identity, const T *partials)
+struct ScanAllTiles { template <typename T> __device__ __forceinline__ bool operator()(u64, T) const { return true; } };
+
+// filter(tile, carry_in): a false answer skips the tile (no loads, no calls of in/out)
+template <typename T, typename Op, typename InF, typename OutF, bool INCLUSIVE, typename Filter>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(u64 n, InF in, OutF out, Op op, T identity, const T *partials, Filter filter)
 {
     __shared__ T sm[SCAN_THREADS / 64];
     __shared__ T tile[SCAN_TILE + SCAN_TILE / 8];
+    if (!filter((u64)blockIdx.x, partials[blockIdx.x])) return;
     const u64 tile_base = (u64)blockIdx.x * SCAN_TILE;
-    // striped (coalesced) load -> LDS
+    // striped (coalesced) load -> LDS; a functor may hand a 32-bit note from its load to its store
+    // (both see the same element in the same lane), e.g. flags that cost a global load to recompute
+    u32 note[SCAN_ITEMS];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
         const u32 e = (u32)j * SCAN_THREADS + threadIdx.x;
         const u64 i = tile_base + e;
-        tile[SCAN_SLOT(e)] = i < n ? in(i) : identity;
+        note[j] = 0;
+        tile[SCAN_SLOT(e)] = i < n ? scan_call_in(in, i, &note[j]) : identity;
     }
     __syncthreads();
     // blocked scan: thread t owns elements [8t, 8t+8)
@@ -95,11 +113,38 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(u64 n, InF in,
     for (int j = 0; j < SCAN_ITEMS; j++) {
         const u32 e = (u32)j * SCAN_THREADS + threadIdx.x;
         const u64 i = tile_base + e;
-        if (i < n) out(i, tile[SCAN_SLOT(e)]);
+        if (i < n) scan_call_out(out, i, tile[SCAN_SLOT(e)], note[j]);
     }
 }
 
-static inline size_t scan_temp_bytes_t(u64 n, size_t elem) { return align_up((size_t)(scan_tiles(n) + 1) * elem, 256); }
+// partials of every level: tiles + tiles/2048 + ... (each level padded)
+static inline size_t scan_temp_bytes_t(u64 n, size_t elem)
+{
+    size_t total = 0;
+    for (u64 t = scan_tiles(n);; t = scan_tiles(t)) {
+        total += align_up((size_t)(t + 1) * elem, 256);
+        if (t <= SCAN_SINGLE_BLOCK_MAX) break;
+    }
+    return total;
+}
+
+template <typename T> struct ScanLoadArr  { const T *p; __device__ __forceinline__ T operator()(u64 i) const { return p[i]; } };
+template <typename T> struct ScanStoreArr { T *p; __device__ __forceinline__ void operator()(u64 i, T v) const { p[i] = v; } };
+
+// exclusive scan of the per-tile reductions already sitting in `temp`
+template <typename T, typename Op>
+static int device_scan_partials(bwts_ctx *ctx, u64 tiles, Op op, T identity, void *temp);
+
+// final sweep only: `temp` holds the scanned per-tile carries
+template <bool INCLUSIVE, typename T, typename Op, typename InF, typename OutF, typename Filter>
+static int device_scan_final(bwts_ctx *ctx, u64 n, InF in, OutF out, Op op, T identity, void *temp, Filter filter)
+{
+    if (n == 0) return BWTS_OK;
+    scan_final_kernel<T, Op, InF, OutF, INCLUSIVE, Filter><<<dim3((unsigned)scan_tiles(n)), dim3(SCAN_THREADS), 0, ctx->stream>>>(
+        n, in, out, op, identity, (const T *)temp, filter);
+    HIPC(hipGetLastError());
+    return BWTS_OK;
+}
 
 // out(i, prefix) is called once per i; in(i) is called twice per i (once per sweep).
 template <bool INCLUSIVE, typename T, typename Op, typename InF, typename OutF>
@@ -109,8 +154,22 @@ static int device_scan(bwts_ctx *ctx, u64 n, InF in, OutF out, Op op, T identity
     const u64 tiles = scan_tiles(n);
     T *partials = (T *)temp;
     scan_reduce_kernel<T, Op, InF><<<dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream>>>(n, in, op, identity, partials);
-    scan_partials_kernel<T, Op><<<dim3(1), dim3(1024), 0, ctx->stream>>>(tiles, op, identity, partials);
-    scan_final_kernel<T, Op, InF, OutF, INCLUSIVE><<<dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, ctx->stream>>>(n, in, out, op, identity, partials);
-    HIPC(hipGetLastError());
-    return BWTS_OK;
+    BWTS_TRY((device_scan_partials<T, Op>(ctx, tiles, op, identity, temp)));
+    return device_scan_final<INCLUSIVE, T>(ctx, n, in, out, op, identity, temp, ScanAllTiles());
+}
+
+template <typename T, typename Op>
+static int device_scan_partials(bwts_ctx *ctx, u64 tiles, Op op, T identity, void *temp)
+{
+    T *partials = (T *)temp;
+    if (tiles <= SCAN_SINGLE_BLOCK_MAX) {
+        scan_partials_kernel<T, Op><<<dim3(1), dim3(1024), 0, ctx->stream>>>(tiles, op, identity, partials);
+        HIPC(hipGetLastError());
+        return BWTS_OK;
+    }
+    // many partials: scan them with the same three-kernel scheme one level up (exclusive, in place)
+    void *next = (char *)temp + align_up((size_t)(tiles + 1) * sizeof(T), 256);
+    ScanLoadArr<T> pin{partials};
+    ScanStoreArr<T> pout{partials};
+    return device_scan<false, T>(ctx, tiles, pin, pout, op, identity, next);
 }
