@@ -151,12 +151,13 @@ __device__ __forceinline__ u64 factor_end(const u32 *__restrict__ fstart, u64 k,
 #define KB_TILE    (KB_THREADS * KB_ITEMS)
 #define KB_HALO    64
 
+// The value array of round 0 is the identity and is never written: the first radix pass uses the element index.
 __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes_g,
                                                                int bits, int msym, int pad_add,
-                                                               u64 *__restrict__ keys, u32 *__restrict__ vals,
-                                                               u64 *__restrict__ tile_min /* may be null */)
+                                                               u64 *__restrict__ keys, u64 *__restrict__ tile_min /* may be null */)
 {
-    __shared__ u16 sc[KB_TILE + KB_HALO];
+    __shared__ u16 sc[KB_TILE + KB_HALO + 16];
+    __shared__ u64 skey[KB_TILE + KB_TILE / 8];     // blocked -> striped transpose (one pad slot per 8)
     __shared__ u8 codes[256];
     __shared__ u64 wmin[KB_THREADS / 64];
 
@@ -168,11 +169,26 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
     const int key_bits = bits * msym;
     const u64 mask = key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull);
 
-    // symbol codes of the tile and its halo; past the end of the text the code is 0
+    // symbol codes of the tile and its halo; past the end of the text the code is 0.  16 bytes per lane
+    // where the text allows it (tile bases are multiples of 2048, device buffers are 16-byte aligned).
     const u32 span = (u32)(end - base) + (u32)msym;
-    for (u32 i = tid; i < span; i += KB_THREADS) {
-        const u64 q = base + i;
-        sc[i] = q < n ? (u16)((u32)codes[T[q]] + (u32)pad_add) : (u16)0;
+    const bool vec_ok = ((uintptr_t)T & 15) == 0;
+    for (u32 c = tid; c * 16 < span; c += KB_THREADS) {
+        const u64 q0 = base + (u64)c * 16;
+        if (vec_ok && q0 + 16 <= n) {
+            const uint4 v = *(const uint4 *)(T + q0);
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++)
+                    sc[c * 16 + a * 4 + bb] = (u16)((u32)codes[(w[a] >> (8 * bb)) & 255u] + (u32)pad_add);
+        } else {
+            for (int bb = 0; bb < 16; bb++) {
+                const u64 q = q0 + bb;
+                sc[c * 16 + bb] = q < n ? (u16)((u32)codes[T[q]] + (u32)pad_add) : (u16)0;
+            }
+        }
     }
     __syncthreads();
     const u32 o = (u32)tid * KB_ITEMS;
@@ -182,26 +198,35 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
         for (int j = 0; j < msym; j++) key = (key << bits) | sc[o + j];
 #pragma unroll
         for (int e = 0; e < KB_ITEMS; e++) {
-            const u64 p = base + o + e;
-            if (p < end) {
-                keys[p] = key;
-                vals[p] = (u32)p;
+            if (base + o + e < end) {
+                skey[o + e + ((o + e) >> 3)] = key;
                 lo = key < lo ? key : lo;
                 key = ((key << bits) | sc[o + e + msym]) & mask;   // stays inside the loaded span / halo
             }
         }
     }
-    // smallest key of the tile: the Lyndon candidate search starts from these (same tile size as the scan)
     if (tile_min) {
         lo = wave_scan_inclusive(lo, OpMin());
         if (lane_id() == 63) wmin[wave_id()] = lo;
-        __syncthreads();
-        if (tid == 0) {
-            u64 t = wmin[0];
-            for (int w = 1; w < KB_THREADS / 64; w++) t = wmin[w] < t ? wmin[w] : t;
-            tile_min[blockIdx.x] = t;
-        }
     }
+    __syncthreads();
+    // lane-consecutive (coalesced) key stores
+#pragma unroll
+    for (int j = 0; j < KB_ITEMS; j++) {
+        const u32 e = (u32)j * KB_THREADS + tid;
+        if (base + e < end) keys[base + e] = skey[e + (e >> 3)];
+    }
+    // smallest key of the tile: the Lyndon candidate search starts from these (same tile size as the scan)
+    if (tile_min && tid == 0) {
+        u64 t = wmin[0];
+        for (int w = 1; w < KB_THREADS / 64; w++) t = wmin[w] < t ? wmin[w] : t;
+        tile_min[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(u32 *__restrict__ v, u64 n)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) v[i] = (u32)i;
 }
 
 // first msym symbols of rot(p)^omega for a position of factor [s, e)
@@ -444,6 +469,11 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     plan.vals[0] = sp.vals[0]; plan.vals[1] = sp.vals[1];
     plan.tile_hist = sp.tile_hist; plan.scan_temp = sp.scan_temp;
     plan.sym_src = sp.carry_src; plan.sym_buf[0] = sp.carry_buf[0]; plan.sym_buf[1] = sp.carry_buf[1]; plan.sym_final = sp.carry_out;
+    plan.vals_identity = radix_supports_sym();     // keybuild0 writes no value array
+    if (!plan.vals_identity) {                     // tuning configs without the identity variant: materialise it
+        u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+        iota_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.vals[0], n);
+    }
     int res = 0;
     BWTS_TRY(radix_sort_pairs(ctx, plan, n, al.key_bits, &res));
     u64 *K0 = sp.keys[res];
@@ -547,10 +577,10 @@ static_assert(KB_TILE == SCAN_TILE, "keybuild0's tile minima feed the scan's fin
 
 static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp, u64 *tile_min)
 {
-    SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + 12 * n);
+    SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + 8 * n);
     const u64 blocks = (n + KB_TILE - 1) / KB_TILE;
     keybuild0_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(
-        d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, sp.keys[0], sp.vals[0], tile_min);
+        d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, sp.keys[0], tile_min);
     HIPC(hipGetLastError());
     return BWTS_OK;
 }

@@ -99,6 +99,7 @@ struct SortPlan {
     const u8 *sym_src = nullptr;     // byte of element i before the first pass
     u8 *sym_buf[2] = {nullptr, nullptr};
     u8 *sym_final = nullptr;         // where the last pass leaves the bytes
+    bool vals_identity = false;      // vals[0] is not read: the first pass uses value = element index
 };
 bool radix_supports_sym(void);       // the byte stream is compiled for the default tile shape only
 u64    radix_tiles(u64 m);

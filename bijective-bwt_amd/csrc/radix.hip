@@ -235,7 +235,7 @@ __global__ __launch_bounds__(RX_THREADS) void radix_scatter_kernel(const u64 *__
 // one-byte stream), the per-wave digit counters are 16-bit and each slot's digit is kept in a byte table, so
 // the destination of a slot is re-derived instead of living in a register: 9 B of LDS per element instead
 // of 12, two 8192-element tiles fit a CU and one tile's loads overlap the other's ranking.
-template <int RX_THREADS, int RX_ITEMS, int MINW, bool HAS_SYM>
+template <int RX_THREADS, int RX_ITEMS, int MINW, bool HAS_SYM, bool IDENT>
 __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
                                                                      u64 *__restrict__ kout, u32 *__restrict__ vout,
                                                                      const u32 *__restrict__ tile_off, u64 m, int shift,
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const u64 i = wave_base + (u64)j * 64 + lane;
-        val[j] = i < m ? vin[i] : 0u;
+        val[j] = IDENT ? (u32)i : (i < m ? vin[i] : 0u);          // first pass of a sort over positions: value = index
     }
     __syncthreads();
 #pragma unroll
@@ -397,17 +397,17 @@ static int launch_scatter_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32 
     return BWTS_OK;
 }
 
-template <int TH, int IT, int MINW, bool HAS_SYM = false>
+template <int TH, int IT, int MINW, bool HAS_SYM = false, bool IDENT = false>
 static int launch_scatter2_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *tile_off,
                              u64 m, int shift, const u8 *sin = nullptr, u8 *sout = nullptr)
 {
     constexpr size_t lds = (size_t)TH * IT * 9 + 2048 + 64 + (size_t)(TH / 64) * 512;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPC(hipFuncSetAttribute((const void *)radix_scatter2_kernel<TH, IT, MINW, HAS_SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPC(hipFuncSetAttribute((const void *)radix_scatter2_kernel<TH, IT, MINW, HAS_SYM, IDENT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    radix_scatter2_kernel<TH, IT, MINW, HAS_SYM><<<dim3((unsigned)rx_grid(tiles)), dim3(TH), lds, ctx->stream>>>(kin, vin, kout, vout, tile_off, m, shift, sin, sout);
+    radix_scatter2_kernel<TH, IT, MINW, HAS_SYM, IDENT><<<dim3((unsigned)rx_grid(tiles)), dim3(TH), lds, ctx->stream>>>(kin, vin, kout, vout, tile_off, m, shift, sin, sout);
     return BWTS_OK;
 }
 
@@ -492,13 +492,23 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
             SpanGuard g(ctx, BWTS_K_RADIX_SCAN, tiles * 256, tiles * 256 * 12);
             BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, plan.scan_temp));
         }
+        const bool ident = plan.vals_identity && p == 0;
         if (plan.sym_src) {
             if (cfg != 8) return BWTS_E_INTERNAL;
             const u8 *sin = p == 0 ? plan.sym_src : plan.sym_buf[(p - 1) & 1];
             u8 *sout = p == passes - 1 ? plan.sym_final : plan.sym_buf[p & 1];
-            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 26 * m);
-            BWTS_TRY((launch_scatter2_t<512, 16, 4, true>(ctx, tiles, plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1], plan.vals[cur ^ 1],
-                                                           tile_hist, m, shift, sin, sout)));
+            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (ident ? 22 : 26) * m);
+            if (ident)
+                BWTS_TRY((launch_scatter2_t<512, 16, 4, true, true>(ctx, tiles, plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1],
+                                                                     plan.vals[cur ^ 1], tile_hist, m, shift, sin, sout)));
+            else
+                BWTS_TRY((launch_scatter2_t<512, 16, 4, true, false>(ctx, tiles, plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1],
+                                                                      plan.vals[cur ^ 1], tile_hist, m, shift, sin, sout)));
+        } else if (ident) {
+            if (cfg != 8) return BWTS_E_INTERNAL;
+            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 20 * m);
+            BWTS_TRY((launch_scatter2_t<512, 16, 4, false, true>(ctx, tiles, plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1], plan.vals[cur ^ 1],
+                                                                  tile_hist, m, shift)));
         } else {
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 24 * m);
             BWTS_TRY(launch_scatter(ctx, cfg, tiles, plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1], plan.vals[cur ^ 1], tile_hist, m,
