@@ -99,35 +99,36 @@ __global__ __launch_bounds__(LF_THREADS) void lf_rank_kernel(const u8 *__restric
 // ------------------------------------------------------------------------------------
 // splitter walk (the only pass that chases LF)
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 symbol_of(const u32 *Ctab, u32 y)
+__device__ __forceinline__ u32 symbol_of(const u64 *Ctab, u32 y)
 {
     // B[x] is the symbol whose C-range holds LF[x]: largest c with Ctab[c] <= y  (Ctab[256] = n)
     u32 lo = 0, hi = 255;
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const u32 mid = (lo + hi + 1) >> 1;
-        if (Ctab[mid] <= y) lo = mid; else hi = mid - 1;
+        if (Ctab[mid] <= (u64)y) lo = mid; else hi = mid - 1;     // 64-bit: boundaries reach n = 2^32
     }
     return lo;
 }
 
 // A lane walks LF from its splitter to the next one.  Along the way it marks the entries it visits (top
-// bit of LF), keeps the smallest index seen, and records the symbols it passes -- B[x] read off LF[x] -- into
+// bit of LF, or a byte map when n >= 2^31), keeps the smallest index seen, and records the symbols it passes -- B[x] read off LF[x] -- into
 // its node's slot of `seg`, 4 at a time.  A walk that reaches `slot` steps without meeting a splitter closes its
 // node there and continues as a fresh virtual node (ids >= s, handed out by an atomic counter), so no segment
 // outgrows its slot.  A wave pulls batches of splitter ids from a shared counter and hands them to its lanes as
 // they finish (one atomic per WALK_BATCH walks); every walk ends at the next splitter (LF is a permutation) and
 // a lane that finds the counter exhausted stops asking, so every wave drains.
 #define WALK_BATCH 128
-__global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, u64 s, u64 node_cap, int g, u32 slot,
-                                                          const u32 *__restrict__ Cg, u8 *__restrict__ seg,
+template <bool BYTEMARK>
+__global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, u8 *__restrict__ marks, u64 s, u64 node_cap, int g, u32 slot,
+                                                          const u64 *__restrict__ Cg, u8 *__restrict__ seg,
                                                           u32 *__restrict__ nxt, u32 *__restrict__ seglen,
                                                           u32 *__restrict__ segmin, u32 *__restrict__ segminoff,
                                                           unsigned long long *__restrict__ ticket,
                                                           unsigned long long *__restrict__ vcount,
                                                           unsigned long long *__restrict__ overflow)
 {
-    __shared__ u32 Ctab[257];
+    __shared__ u64 Ctab[257];
     for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
     __syncthreads();
     const u32 gmask = (1u << g) - 1u;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
         if (__ballot(have || !done) == 0) break;     // every lane has seen the counter run dry
         if (have) {
             const u32 y = LF[x];
-            LF[x] = y | LF_TOP;
+            if (BYTEMARK) marks[x] = 1; else LF[x] = y | LF_TOP;      // n >= 2^31 needs all 32 bits of LF: marks live in a byte map
             {
                 const u32 sh = symbol_of(Ctab, y) << (8 * (len & 3u));
                 const u32 w = (len >> 2) & 3u;
@@ -209,13 +210,19 @@ __global__ __launch_bounds__(256) void place_segments_kernel(const u8 *__restric
 // ------------------------------------------------------------------------------------
 // elements no walk reached (cycles without a splitter): one sweep, wave-aggregated append
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void collect_unvisited_kernel(const u32 *__restrict__ LF, u64 n, u32 *__restrict__ uidx,
-                                                                u32 *__restrict__ ulf, u64 cap, unsigned long long *__restrict__ count)
+template <bool BYTEMARK>
+__global__ __launch_bounds__(256) void collect_unvisited_kernel(const u32 *__restrict__ LF, const u8 *__restrict__ marks, u64 n,
+                                                                u32 *__restrict__ uidx, u32 *__restrict__ ulf, u64 cap,
+                                                                unsigned long long *__restrict__ count)
 {
     for (u64 base = (u64)blockIdx.x * 256; base < n; base += (u64)gridDim.x * 256) {
         const u64 i = base + threadIdx.x;
-        const u32 v = i < n ? LF[i] : LF_TOP;
-        const bool un = !(v & LF_TOP);
+        bool un = false;
+        u32 v = 0;
+        if (i < n) {
+            if (BYTEMARK) { un = marks[i] == 0; if (un) v = LF[i]; }
+            else { v = LF[i]; un = !(v & LF_TOP); }
+        }
         const u64 m = __ballot(un);
         if (m) {
             const int leader = __ffsll((unsigned long long)m) - 1;
@@ -368,7 +375,8 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     const u64 node_cap = g == 0 ? s : s + s / 8 + 1024;
     const size_t s4 = align_up(node_cap * 4, 256);
     BWTS_TRY(arena_reserve(ctx, align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 24 * s4 +
-                                    align_up(node_cap * sizeof(CycleRec), 256) + align_up(node_cap * slot, 256) + (1 << 16)));
+                                    align_up(node_cap * sizeof(CycleRec), 256) + align_up(node_cap * slot, 256) + align_up(n, 256) +
+                                    (1 << 16)));
     u32 *LF = arena_array<u32>(ctx, n);
     u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
     void *scan_temp = arena_alloc(ctx, scan_temp_bytes(n));
@@ -376,7 +384,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     for (int i = 0; i < 20; i++) node[i] = arena_array<u32>(ctx, node_cap);
     CycleRec *d_recs = (CycleRec *)arena_alloc(ctx, node_cap * sizeof(CycleRec));
     u8 *seg = arena_array<u8>(ctx, node_cap * slot);
-    if (!LF || !tile_hist || !scan_temp || !node[19] || !d_recs || !seg) return BWTS_E_NOMEM;
+    const bool bytemark = n >= 0x80000000ull || getenv("BWTS_BYTEMARK") != nullptr;   // LF values need bit 31 (env: test hook)
+    u8 *marks = bytemark ? arena_array<u8>(ctx, n) : nullptr;
+    if (!LF || !tile_hist || !scan_temp || !node[19] || !d_recs || !seg || (bytemark && !marks)) return BWTS_E_NOMEM;
+    if (bytemark) HIPC(hipMemsetAsync(marks, 0, n, ctx->stream));
     u32 *nxt = node[0], *seglen = node[1], *segmin = node[2], *segoff = node[3];
     u32 *d_opos = node[4], *d_wrap = node[5], *d_clen = node[6];
     u32 *lead[2] = {node[7], node[8]}, *cmin[2] = {node[9], node[10]}, *hop[2] = {node[11], node[12]};
@@ -386,15 +397,15 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     // symbol boundaries C[0..256] on the host (unbwts.c:38-43)
     BWTS_TRY(byte_histogram_device(ctx, d_in, n, ctx->d_small + SMI_HIST));
     BWTS_TRY(read_small(ctx, SMI_HIST, 256));
-    u32 *hC = (u32 *)(ctx->h_small + 1024);
+    u64 *hC = ctx->h_small + 1024;
     {
         u64 acc = 0;
-        for (int c = 0; c < 256; c++) { hC[c] = (u32)acc; acc += ctx->h_small[SMI_HIST + c]; }
-        hC[256] = (u32)acc;
+        for (int c = 0; c < 256; c++) { hC[c] = acc; acc += ctx->h_small[SMI_HIST + c]; }
+        hC[256] = acc;
         if (acc != n) return BWTS_E_INTERNAL;
     }
-    u32 *dC = (u32 *)(ctx->d_small + 1024);
-    HIPC(hipMemcpyAsync(dC, hC, 257 * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    u64 *dC = ctx->d_small + 1024;
+    HIPC(hipMemcpyAsync(dC, hC, 257 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
 
     // stable LF map (unbwts.c:50-52)
     {
@@ -412,8 +423,12 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     const unsigned wblocks = (unsigned)((walkers + 255) / 256);
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 6 * n);
-        walk_record_kernel<<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, s, node_cap, g, slot, dC, seg, nxt, seglen, segmin, segoff,
-                                                                        ticket, ticket + 3, ticket + 4);
+        if (bytemark)
+            walk_record_kernel<true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, s, node_cap, g, slot, dC, seg, nxt, seglen, segmin,
+                                                                                  segoff, ticket, ticket + 3, ticket + 4);
+        else
+            walk_record_kernel<false><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, s, node_cap, g, slot, dC, seg, nxt, seglen, segmin,
+                                                                                   segoff, ticket, ticket + 3, ticket + 4);
         HIPC(hipGetLastError());
     }
     // virtual nodes join the reduced list: its size is only known now
@@ -428,7 +443,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     {
         SpanGuard sg(ctx, BWTS_K_OTHER, n, 4 * n);
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
-        collect_unvisited_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, n, uidx, ulf, UNV_CAP, ticket + 1);
+        if (bytemark)
+            collect_unvisited_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, UNV_CAP, ticket + 1);
+        else
+            collect_unvisited_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, UNV_CAP, ticket + 1);
         HIPC(hipGetLastError());
     }
 
@@ -543,7 +561,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         h_upos.resize(nu); h_usym.resize(nu);
         for (u64 q = 0; q < nu; q++) {
             h_upos[q] = cyc_end[u_cyc[q]] - u_t[q];
-            const u32 *it = std::upper_bound(hC, hC + 257, h_ulf[q]);
+            const u64 *it = std::upper_bound(hC, hC + 257, (u64)h_ulf[q]);
             h_usym[q] = (u8)((it - hC) - 1);
         }
         u32 *d_upos = uidx;                                           // the index list is no longer needed
@@ -559,7 +577,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
 
 int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
-    if (n >= 0x80000000ull) return BWTS_E_RANGE;
+    if (n > 0x100000000ull) return BWTS_E_RANGE;
     bool retry = false;
     BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), &retry));
     if (retry) {

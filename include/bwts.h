@@ -33,7 +33,7 @@ extern "C" {
 #define BWTS_E_NODEVICE -2   /* no HIP device / device id out of range */
 #define BWTS_E_NOMEM    -3   /* device or pinned-host allocation failed */
 #define BWTS_E_HIP      -4   /* a HIP runtime call failed; see bwts_last_hip_error() */
-#define BWTS_E_RANGE    -5   /* n beyond what the engine indexes (n > 2^32 forward, n >= 2^31 inverse) */
+#define BWTS_E_RANGE    -5   /* n beyond what the engine indexes (n > 2^32) */
 #define BWTS_E_INTERNAL -6   /* engine invariant violated (bug) */
 
 typedef struct bwts_ctx bwts_ctx;

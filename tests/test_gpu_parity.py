@@ -199,6 +199,23 @@ def test_config3_zipf_1GiB_properties(ctx):
     _properties_at_scale(ctx, "zipf", 1 << 30, 1)
 
 
+def test_index_boundary_2p31(ctx):
+    """n just above 2^31: the inverse keeps its marks in a byte map, LF uses all 32 bits."""
+    _properties_at_scale(ctx, "zipf", (1 << 31) + 12345, 3)
+
+
+def test_config4_dna_4GiB_properties(ctx, pkg):
+    """BASELINE config 4: dna(2^32).  Beyond the reference's 32-bit indices (mk_bwts_sa.c:26-27, unbwts.c:12-13), so parity
+    is by properties only: round trip both ways, byte histogram preserved, bwts[0] = T[n-1]."""
+    try:
+        tf = _properties_at_scale(ctx, "dna", 1 << 32, 1)
+    except pkg.BwtsError as e:
+        if e.code == -3:
+            pytest.skip("not enough free device memory for the 4 GiB case")
+        raise
+    assert tf.key_symbols == 32 and tf.key_bits == 64      # sigma = 4: 2 bits per symbol, 32 symbols per key
+
+
 def test_forward_prefix_consistency_64MiB(ctx):
     """Checksum-of-checksums: 64 MiB zipf forward equals the oracle's (sha256 compared)."""
     n = 1 << 26
