@@ -91,7 +91,7 @@ def main(argv=None):
     ap.add_argument("--workload", default="zipf", choices=["zipf", "uniform256", "dna"])
     ap.add_argument("--log2n", type=int, default=30)
     ap.add_argument("--inverse-steps", type=int, default=2)
-    ap.add_argument("--cpu-sample-log2n", type=int, default=25)
+    ap.add_argument("--cpu-sample-log2n", type=int, default=26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--selftest-sleep-ms", type=float, default=0.0,
                     help="harness self-test (tests/test_dist_cpu.py): no GPU, no transform; every step sleeps "
@@ -187,8 +187,16 @@ def main(argv=None):
                                  "alg_GBps": round(st["alg_bytes"] / 1e9 / (st["ms"] / 1e3), 1)}
             return out
 
-        sc = agg.get("radix_scatter", {"ms": 0.0, "launches": 0, "alg_bytes": 0})
+        # dominant kernel: the n-sized LSD passes of round 0 (one template variant, timed under its own class)
+        sc = agg.get("radix_scatter_main") or agg.get("radix_scatter", {"ms": 0.0, "launches": 0, "alg_bytes": 0})
         achieved = sc["alg_bytes"] / 1e9 / (sc["ms"] / 1e3) if sc["ms"] > 0 else 0.0
+        traffic = None
+        try:    # PMC bytes per launch, collected with rocprofv3 --pmc on this workload (profiles/), only valid for 2^30
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_radix_scatter.json")))
+            if args.log2n == 30 and args.workload == "zipf":
+                traffic = pm["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         line = {
             "metric": "BWTS build MB/s on 1 GiB input (+ inverse MB/s); bit-exact round-trip",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -198,8 +206,9 @@ def main(argv=None):
                        "bytes_per_gpu": n, "parallelism": "replicas x%d (one input per GPU, RCCL barrier only)" % n_gpus},
             "inverse_MBps": round(inv_value, 2), "inverse_ms_per_step": round(1e3 * inv_s / max(args.inverse_steps, 1), 3),
             "roundtrip_exact": bad == 0.0,
-            "roofline": {"bound": "hbm", "kernel": "radix_scatter_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "radix_scatter2_kernel<512,16,4,true,false> (8-bit LSD pass, key 8 B + value 4 B + carried byte)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": sc["alg_bytes"] // max(sc["launches"], 1),
                          "ms_per_launch": round(sc["ms"] / max(sc["launches"], 1), 4), "launches": sc["launches"]},
             "forward": {"factors": fwd_info["factors"], "rounds": fwd_info["rounds"], "lyndon_rounds": fwd_info["lyndon_rounds"],

@@ -70,25 +70,26 @@ void spans_reset(bwts_ctx *ctx)
     memset(&ctx->tm, 0, sizeof(ctx->tm));
 }
 
-void span_begin(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes)
+int span_begin(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes)
 {
     ctx->tm.k[cls].launches++;
     ctx->tm.k[cls].elems += elems;
     ctx->tm.k[cls].alg_bytes += alg_bytes;
-    if (!ctx->timing) return;
+    if (!ctx->timing) return -1;
     TimedSpan sp;
     sp.cls = cls;
     sp.a = take_event(ctx);
     sp.b = take_event(ctx);
-    if (!sp.a || !sp.b) return;
+    if (!sp.a || !sp.b) return -1;
     (void)hipEventRecord(sp.a, ctx->stream);
     ctx->spans.push_back(sp);
+    return (int)ctx->spans.size() - 1;
 }
 
-void span_end(bwts_ctx *ctx)
+void span_end(bwts_ctx *ctx, int span)
 {
-    if (!ctx->timing || ctx->spans.empty()) return;
-    (void)hipEventRecord(ctx->spans.back().b, ctx->stream);
+    if (span < 0 || (size_t)span >= ctx->spans.size()) return;
+    (void)hipEventRecord(ctx->spans[span].b, ctx->stream);
 }
 
 int spans_resolve(bwts_ctx *ctx)
@@ -298,7 +299,7 @@ extern "C" int bwts_last_timings(bwts_ctx *ctx, bwts_timings *t)
 extern "C" const char *bwts_kernel_class_name(int k)
 {
     static const char *names[BWTS_K_COUNT] = {"histogram", "keybuild", "radix_hist", "radix_scan", "radix_scatter", "rerank",
-                                              "lyndon", "emit", "lf_build", "walk", "listrank", "walk_emit", "other"};
+                                              "lyndon", "emit", "lf_build", "walk", "listrank", "walk_emit", "other", "radix_scatter_main"};
     return (k >= 0 && k < BWTS_K_COUNT) ? names[k] : "?";
 }
 

@@ -71,15 +71,16 @@ template <typename T> static inline T *arena_array(bwts_ctx *ctx, u64 count)
 }
 
 // ---- timing ------------------------------------------------------------------
-void span_begin(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes);
-void span_end(bwts_ctx *ctx);
+int  span_begin(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes);   // returns a span handle (spans may nest)
+void span_end(bwts_ctx *ctx, int span);
 void spans_reset(bwts_ctx *ctx);
 int  spans_resolve(bwts_ctx *ctx);
 
 struct SpanGuard {
     bwts_ctx *c;
-    SpanGuard(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes) : c(ctx) { span_begin(ctx, cls, elems, alg_bytes); }
-    ~SpanGuard() { span_end(c); }
+    int h;
+    SpanGuard(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes) : c(ctx), h(span_begin(ctx, cls, elems, alg_bytes)) {}
+    ~SpanGuard() { span_end(c, h); }
 };
 
 // ---- read-back of a few u64 words (synchronises the stream) --------------------

@@ -47,12 +47,13 @@ enum {
     BWTS_K_RADIX_SCATTER,   /* ranked, LDS-staged scatter of one LSD pass (dominant)      */
     BWTS_K_RERANK,          /* group flags + head scan + rank scatter + active compaction */
     BWTS_K_LYNDON,          /* prefix-min scan over suffix ranks -> factor heads          */
-    BWTS_K_EMIT,            /* bwts[r] = T[cprev(sa[r])] gather (mk_bwts_sa.c:172-188)     */
+    BWTS_K_EMIT,            /* bwts[r] = T[cprev(sa[r])]: patch of tied slots, or full gather (mk_bwts_sa.c:172-188) */
     BWTS_K_LF_BUILD,        /* stable LF map (unbwts.c:50-52)                              */
-    BWTS_K_WALK,            /* splitter walk over LF cycles, pass 1 (unbwts.c:66-86)       */
+    BWTS_K_WALK,            /* splitter walk over LF cycles, records segments (unbwts.c:66-86) */
     BWTS_K_LISTRANK,        /* reduced-list ranking of splitter nodes                     */
-    BWTS_K_WALK_EMIT,       /* splitter walk, pass 2: writes the text                     */
+    BWTS_K_WALK_EMIT,       /* placement of the recorded segments into the text            */
     BWTS_K_OTHER,
+    BWTS_K_RADIX_SCATTER_MAIN, /* subset of RADIX_SCATTER: passes 1.. of the n-sized round-0 sort (one kernel variant) */
     BWTS_K_COUNT
 };
 
