@@ -314,20 +314,19 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
     }
     // the keys' registers are free: the value (and byte) loads overlap the key write-out
     u32 val[RX_ITEMS];
-    u32 symp[(RX_ITEMS + 3) / 4];
+    u32 sym[HAS_SYM ? RX_ITEMS : 1];
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const u64 i = wave_base + (u64)j * 64 + lane;
         val[j] = IDENT ? (u32)i : (i < m ? vin[i] : 0u);          // first pass of a sort over positions: value = index
     }
     if (HAS_SYM) {
-#pragma unroll
-        for (int q = 0; q < (RX_ITEMS + 3) / 4; q++) symp[q] = 0;
+        // one register per byte and no arithmetic on them here: the 16 loads issue back to back (packing them
+        // on arrival made the compiler wait for memory after every two or three loads)
 #pragma unroll
         for (int j = 0; j < RX_ITEMS; j++) {
             const u64 i = wave_base + (u64)j * 64 + lane;
-            const u32 b = i < m ? (u32)sin[i] : 0u;
-            symp[j >> 2] |= b << (8 * (j & 3));
+            sym[j] = i < m ? (u32)sin[i] : 0u;
         }
     }
     __syncthreads();
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
         const bool valid = wave_base + (u64)j * 64 + lane < m;
         const u32 p = (j & 1) ? posp[j >> 1] >> 16 : posp[j >> 1] & 0xffffu;
         if (valid) {
-            if (HAS_SYM) stage[p] = (u64)val[j] | ((u64)((symp[j >> 2] >> (8 * (j & 3))) & 255u) << 32);
+            if (HAS_SYM) stage[p] = (u64)val[j] | ((u64)sym[j] << 32);
             else ((u32 *)stage)[p] = val[j];
         }
     }
