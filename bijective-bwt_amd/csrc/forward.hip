@@ -331,34 +331,46 @@ struct OpHeadCount {
 };
 
 // The scan kernels visit element i = tile_base + j * 256 + tid, so the neighbouring keys K[i-1], K[i+1]
-// sit in the neighbouring lanes: one global load per element, the wave's two edge lanes load theirs.
-__device__ __forceinline__ void group_flags(const u64 *__restrict__ K, u64 i, u64 a, u64 *ki_out, bool *f0, bool *f1, bool *same_old,
-                                            int rb)
-{
-    const u64 ki = K[i];
-    const int lane = lane_id();
-    const u64 act = __ballot(true);                       // lanes that hold an element (the tail tile is ragged)
-    u64 kp = shfl_up_t(ki, 1), kn = shfl_down_t(ki, 1);
-    if (lane == 0 && i > 0) kp = K[i - 1];
-    const bool next_here = lane < 63 && ((act >> ((lane + 1) & 63)) & 1ull);
-    if (!next_here && i + 1 < a) kn = K[i + 1];
-    *f0 = i == 0 || ki != kp;
-    *f1 = i + 1 == a || kn != ki;
-    *same_old = rb >= 0 && i > 0 && (ki >> rb) == (kp >> rb);
-    *ki_out = ki;
-}
+// sit in the neighbouring lanes: one global load per element; the wave's two edge lanes fetch the key across
+// the wave boundary with a second, predicated load.  Loads are split from their use (load()/make()) so that a
+// thread's eight loads are all in flight before the first flag is computed.
+struct GroupRaw { u64 k, edge; u32 slot; };
 
 struct GroupIn {
     const u64 *K; const u32 *S; u64 a; int rb;     // S == nullptr: slot(i) = i (round 0)
-    __device__ __forceinline__ u64 operator()(u64 i, u32 *note) const
+    __device__ __forceinline__ GroupRaw load(u64 i) const
     {
-        u64 ki; bool f0, f1, so;
-        group_flags(K, i, a, &ki, &f0, &f1, &so, rb);
-        *note = (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (so ? 4u : 0u);
-        const u32 hv = f0 ? (S ? S[i] : (u32)i) : 0u;
-        return ((u64)hv << 32) | (u64)((f0 && f1) ? 0u : 1u);
+        GroupRaw r;
+        r.k = K[i];
+        const int lane = lane_id();
+        const u64 act = __ballot(true);                       // lanes that hold an element (the tail tile is ragged)
+        const bool next_here = lane < 63 && ((act >> ((lane + 1) & 63)) & 1ull);
+        r.edge = 0;
+        if (lane == 0 && i > 0) r.edge = K[i - 1];
+        if (lane != 0 && !next_here && i + 1 < a) r.edge = K[i + 1];
+        r.slot = S ? S[i] : (u32)i;
+        return r;
     }
-    __device__ __forceinline__ u64 operator()(u64 i) const { u32 note; return (*this)(i, &note); }
+    __device__ __forceinline__ u64 make(u64 i, const GroupRaw &r, u32 *note) const
+    {
+        const u64 ki = r.k;
+        const int lane = lane_id();
+        const u64 act = __ballot(true);
+        const bool next_here = lane < 63 && ((act >> ((lane + 1) & 63)) & 1ull);
+        u64 kp = shfl_up_t(ki, 1), kn = shfl_down_t(ki, 1);
+        if (lane == 0) kp = r.edge;                           // lane 0 is never also the last holder unless alone; see below
+        if (!next_here) kn = r.edge;
+        // a lane that is both first and last (single active lane) has only one edge slot: its successor is out of range
+        // or in the next wave; that only happens in the ragged tail, where lane 0's successor is loaded here
+        if (lane == 0 && !next_here && i + 1 < a) kn = K[i + 1];
+        const bool f0 = i == 0 || ki != kp;
+        const bool f1 = i + 1 == a || kn != ki;
+        const bool so = rb >= 0 && i > 0 && (ki >> rb) == (kp >> rb);
+        *note = (f0 ? 1u : 0u) | (f1 ? 2u : 0u) | (so ? 4u : 0u);
+        return ((u64)(f0 ? r.slot : 0u) << 32) | (u64)((f0 && f1) ? 0u : 1u);
+    }
+    __device__ __forceinline__ u64 operator()(u64 i, u32 *note) const { return make(i, load(i), note); }
+    __device__ __forceinline__ u64 operator()(u64 i) const { u32 note; return make(i, load(i), &note); }
 };
 
 struct GroupOut {

@@ -40,10 +40,16 @@ __global__ __launch_bounds__(LF_THREADS) void lf_hist_kernel(const u8 *__restric
     for (int i = tid; i < LF_WAVES * 256; i += LF_THREADS) ((u32 *)bins)[i] = 0;
     __syncthreads();
     const u64 base = (u64)blockIdx.x * LF_TILE;
+    u32 sy[LF_ITEMS];                     // loads first, LDS atomics after: 16 loads in flight per lane
 #pragma unroll
     for (int j = 0; j < LF_ITEMS; j++) {
         const u64 i = base + (u64)j * LF_THREADS + tid;
-        if (i < n) atomicAdd(&bins[w][B[i]], 1u);
+        sy[j] = i < n ? (u32)B[i] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < LF_ITEMS; j++) {
+        const u64 i = base + (u64)j * LF_THREADS + tid;
+        if (i < n) atomicAdd(&bins[w][sy[j]], 1u);
     }
     __syncthreads();
     u32 s = 0;

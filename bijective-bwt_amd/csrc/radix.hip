@@ -89,13 +89,17 @@ __global__ __launch_bounds__(RX_THREADS) void radix_hist_kernel(const u64 *__res
     for (int i = tid; i < RX_WAVES * 256; i += RX_THREADS) ((u32 *)bins)[i] = 0;
     __syncthreads();
     const u64 base = (u64)blockIdx.x * RX_TILE;
+    // all loads first (one register pair each), then the LDS atomics: keeps 16 loads in flight per lane
+    u64 k[RX_ITEMS];
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const u64 i = base + (u64)j * RX_THREADS + tid;
-        if (i < m) {
-            const u32 d = (u32)(keys[i] >> shift) & 255u;
-            atomicAdd(&bins[w][d], 1u);
-        }
+        k[j] = i < m ? keys[i] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const u64 i = base + (u64)j * RX_THREADS + tid;
+        if (i < m) atomicAdd(&bins[w][(u32)(k[j] >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (tid < 256) {

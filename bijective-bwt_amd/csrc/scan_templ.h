@@ -11,6 +11,32 @@
 
 static inline u64 scan_tiles(u64 n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
 
+// functors either take (i) / (i, value) or, to pass a note from load to store, (i, u32*) / (i, value, u32)
+template <int N> struct scan_rank : scan_rank<N - 1> {};
+template <> struct scan_rank<0> {};
+template <typename F> __device__ __forceinline__ auto scan_call_in_(const F &f, u64 i, u32 *note, scan_rank<1>) -> decltype(f(i, note)) { return f(i, note); }
+template <typename F> __device__ __forceinline__ auto scan_call_in_(const F &f, u64 i, u32 *, scan_rank<0>) -> decltype(f(i)) { return f(i); }
+template <typename F, typename T> __device__ __forceinline__ auto scan_call_out_(const F &f, u64 i, T v, u32 note, scan_rank<1>) -> decltype(f(i, v, note)) { return f(i, v, note); }
+template <typename F, typename T> __device__ __forceinline__ auto scan_call_out_(const F &f, u64 i, T v, u32, scan_rank<0>) -> decltype(f(i, v)) { return f(i, v); }
+#define scan_call_in(f, i, note) scan_call_in_(f, i, note, scan_rank<1>())
+
+// A functor may split its work into load(i) -> Raw (global loads only) and make(i, raw, note) -> T, so that the
+// kernels can issue all of a thread's loads back to back before any of them is consumed.
+template <typename F> struct scan_raw_of {
+    template <typename G> static auto probe(int) -> decltype(((const G *)nullptr)->load((u64)0));
+    template <typename G> static char probe(...);
+    typedef decltype(probe<F>(0)) type;       // char = no load()
+};
+template <typename F, typename T>
+__device__ __forceinline__ auto scan_load_(const F &f, u64 i, scan_rank<1>) -> decltype(f.load(i)) { return f.load(i); }
+template <typename F, typename T>
+__device__ __forceinline__ char scan_load_(const F &, u64, scan_rank<0>) { return 0; }
+template <typename F, typename R, typename T>
+__device__ __forceinline__ auto scan_make_(const F &f, u64 i, const R &raw, u32 *note, scan_rank<1>) -> decltype(f.make(i, raw, note)) { return f.make(i, raw, note); }
+template <typename F, typename R, typename T>
+__device__ __forceinline__ T scan_make_(const F &f, u64 i, const R &, u32 *note, scan_rank<0>) { return scan_call_in(f, i, note); }
+#define scan_call_out(f, i, v, note) scan_call_out_(f, i, v, note, scan_rank<1>())
+
 // Both sweeps touch element i = tile_base + j * SCAN_THREADS + tid (lane-consecutive, coalesced);
 // the ops used here are commutative, so the reduce sweep may combine in that order.
 template <typename T, typename Op, typename InF>
@@ -19,10 +45,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(u64 n, InF in
     __shared__ T sm[SCAN_THREADS / 64];
     const u64 base = (u64)blockIdx.x * SCAN_TILE + threadIdx.x;
     T acc = identity;
+    typename scan_raw_of<InF>::type raw[SCAN_ITEMS];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
         const u64 i = base + (u64)j * SCAN_THREADS;
-        if (i < n) acc = op(acc, in(i));
+        if (i < n) raw[j] = scan_load_<InF, T>(in, i, scan_rank<1>());
+    }
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        const u64 i = base + (u64)j * SCAN_THREADS;
+        u32 note;
+        if (i < n) acc = op(acc, scan_make_<InF, typename scan_raw_of<InF>::type, T>(in, i, raw[j], &note, scan_rank<1>()));
     }
     T inc = wave_scan_inclusive(acc, op);
     if (lane_id() == 63) sm[wave_id()] = inc;
@@ -50,16 +83,6 @@ __global__ __launch_bounds__(1024) void scan_partials_kernel(u64 count, Op op, T
     }
 }
 
-// functors either take (i) / (i, value) or, to pass a note from load to store, (i, u32*) / (i, value, u32)
-template <int N> struct scan_rank : scan_rank<N - 1> {};
-template <> struct scan_rank<0> {};
-template <typename F> __device__ __forceinline__ auto scan_call_in_(const F &f, u64 i, u32 *note, scan_rank<1>) -> decltype(f(i, note)) { return f(i, note); }
-template <typename F> __device__ __forceinline__ auto scan_call_in_(const F &f, u64 i, u32 *, scan_rank<0>) -> decltype(f(i)) { return f(i); }
-template <typename F, typename T> __device__ __forceinline__ auto scan_call_out_(const F &f, u64 i, T v, u32 note, scan_rank<1>) -> decltype(f(i, v, note)) { return f(i, v, note); }
-template <typename F, typename T> __device__ __forceinline__ auto scan_call_out_(const F &f, u64 i, T v, u32, scan_rank<0>) -> decltype(f(i, v)) { return f(i, v); }
-#define scan_call_in(f, i, note) scan_call_in_(f, i, note, scan_rank<1>())
-#define scan_call_out(f, i, v, note) scan_call_out_(f, i, v, note, scan_rank<1>())
-
 // LDS slot of tile element e: one pad slot per 8 keeps the blocked (8 per thread) accesses
 // spread over the banks
 #define SCAN_SLOT(e) ((e) + ((e) >> 3))
@@ -77,12 +100,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(u64 n, InF in,
     // striped (coalesced) load -> LDS; a functor may hand a 32-bit note from its load to its store
     // (both see the same element in the same lane), e.g. flags that cost a global load to recompute
     u32 note[SCAN_ITEMS];
+    {
+        typename scan_raw_of<InF>::type raw[SCAN_ITEMS];
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-        const u32 e = (u32)j * SCAN_THREADS + threadIdx.x;
-        const u64 i = tile_base + e;
-        note[j] = 0;
-        tile[SCAN_SLOT(e)] = i < n ? scan_call_in(in, i, &note[j]) : identity;
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+            const u64 i = tile_base + (u32)j * SCAN_THREADS + threadIdx.x;
+            if (i < n) raw[j] = scan_load_<InF, T>(in, i, scan_rank<1>());
+        }
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+            const u32 e = (u32)j * SCAN_THREADS + threadIdx.x;
+            const u64 i = tile_base + e;
+            note[j] = 0;
+            tile[SCAN_SLOT(e)] = i < n ? scan_make_<InF, typename scan_raw_of<InF>::type, T>(in, i, raw[j], &note[j], scan_rank<1>()) : identity;
+        }
     }
     __syncthreads();
     // blocked scan: thread t owns elements [8t, 8t+8)
