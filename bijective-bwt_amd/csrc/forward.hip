@@ -396,10 +396,13 @@ struct GroupOut {
         // number of still-tied elements = inclusive count at the last element (no atomics on the n-sized round);
         // a count of exactly 2^32 wraps to 0 with the last element tied
         if (i + 1 == a) *cnt_active = ((u32)v == 0u && keep) ? 0x100000000ull : (u64)(u32)v;
+        // "did any group split this round?" is all the driver needs: one plain store per wave, and none once the
+        // flag is visibly set (counting with atomics serialised millions of waves on one address in deep rounds)
         if (rb >= 0) {
             const u64 ms = __ballot(f0 && same_old);
-            if (ms && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1)
-                atomicAdd((unsigned long long *)cnt_splits, (unsigned long long)__popcll(ms));
+            if (ms && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1 &&
+                __hip_atomic_load(cnt_splits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __hip_atomic_store(cnt_splits, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 };
@@ -672,7 +675,7 @@ static int lyndon_general(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, u3
 // in K(p)) proves it; equality -- or fill -- is settled by an exact comparison with the latest
 // factor start.  Prefix-min scan over the round-0 keys -> candidate list -> one workgroup.
 #define LYN_CAND_CAP   65536ull
-#define LYN_WORK_CAP   (32ull << 20)      // bytes compared by the resolver before it gives up
+#define LYN_WORK_CAP   (64ull << 20)      // bytes compared inside the resolver workgroup before it gives up
 
 struct KeyIn { const u64 *K; __device__ __forceinline__ u64 operator()(u64 i) const { return K[i]; } };
 struct CandOut {
@@ -700,21 +703,38 @@ struct TileMayHoldCandidate {
     __device__ __forceinline__ bool operator()(u64 t, u64 min_before) const { return tile_min[t] <= min_before; }
 };
 
-// one workgroup walks the position-sorted candidates; exact suffix comparison is block-wide
+// one workgroup walks the position-sorted candidates; exact suffix comparison is block-wide.  A comparison
+// that is still undecided after LYN_LOCAL_LCE bytes is handed to the host, which runs it on the whole chip
+// (suffix_less_grid_kernel) and restarts the walk behind that candidate.
+#define LYN_LOCAL_LCE  (64u << 10)
+struct LynState {         // in d_small: resumable state of the resolver
+    u64 next;             // next candidate to look at
+    u64 cur;              // latest factor start
+    u64 k;                // factor starts found so far
+    u64 status;           // 0 = finished, 1 = long comparison wanted (candidate `next`), 2 = work cap exceeded
+    u64 forced;           // 1: the host has decided candidate `next`: forced_less says whether it starts a factor
+    u64 forced_less;
+    u64 work;
+};
+
 __global__ __launch_bounds__(256) void lyndon_resolve_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ cand, u64 cnt,
-                                                             u32 *__restrict__ fstart, u64 *__restrict__ out_k, u64 *__restrict__ out_ovf,
-                                                             u64 work_cap)
+                                                             u32 *__restrict__ fstart, LynState *__restrict__ st, u64 work_cap)
 {
     __shared__ int s_mis[4];      // per wave: first mismatching lane of the chunk, or -1
     __shared__ int s_less[4];     // per wave: candidate byte < current-start byte at that lane
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    u64 cur = 0, k = 0, work = 0;
-    for (u64 c = 0; c < cnt; c++) {
+    u64 cur = st->cur, k = st->k, work = st->work;
+    const u64 first = st->next;
+    const bool forced = st->forced != 0, forced_less = st->forced_less != 0;
+    __syncthreads();
+    for (u64 c = first; c < cnt; c++) {
         const u64 e = cand[c];
         const u64 p = e >> 1;
         bool is_start;
         if (p == 0 || (e & 1)) {
             is_start = true;
+        } else if (forced && c == first) {
+            is_start = forced_less;
         } else {
             is_start = false;
             for (u64 off = 0;; off += 256) {
@@ -732,7 +752,10 @@ __global__ __launch_bounds__(256) void lyndon_resolve_kernel(const u8 *__restric
                 __syncthreads();
                 work += 256;
                 if (found >= 0) { is_start = less != 0; break; }
-                if (work > work_cap) { if (tid == 0) *out_ovf = 1; return; }
+                if (off + 256 >= LYN_LOCAL_LCE || work > work_cap) {
+                    if (tid == 0) { st->next = c; st->cur = cur; st->k = k; st->work = work; st->forced = 0; st->status = work > work_cap ? 2 : 1; }
+                    return;
+                }
             }
         }
         if (is_start) {
@@ -741,7 +764,18 @@ __global__ __launch_bounds__(256) void lyndon_resolve_kernel(const u8 *__restric
             cur = p;
         }
     }
-    if (tid == 0) *out_k = k;
+    if (tid == 0) { st->next = cnt; st->cur = cur; st->k = k; st->work = work; st->forced = 0; st->status = 0; }
+}
+
+// first position where T[p..] and T[q..] differ (q < p), over the whole chip: result[0] = min mismatch offset
+__global__ __launch_bounds__(256) void suffix_mismatch_grid_kernel(const u8 *__restrict__ T, u64 n, u64 p, u64 q,
+                                                                   unsigned long long *__restrict__ result)
+{
+    const u64 len = n - p;                  // p's suffix is the shorter one; offset len is a mismatch by definition
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < len; i += (u64)gridDim.x * 256) {
+        if (i >= __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;     // someone found an earlier one
+        if (T[p + i] != T[q + i]) { atomicMin(result, (unsigned long long)i); break; }
+    }
 }
 
 // returns BWTS_OK with *done = false when the input needs the general path
@@ -774,15 +808,49 @@ static int lyndon_fast(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, 
     cp.tile_hist = sp.tile_hist; cp.scan_temp = sp.scan_temp;
     int res = 0;
     BWTS_TRY(radix_sort_pairs(ctx, cp, cnt_c, bitlen_u64(n) + 1, &res));
-    {
-        SpanGuard g(ctx, BWTS_K_LYNDON, cnt_c, 0);
-        lyndon_resolve_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(d_T, n, cand[res], cnt_c, fstart, ctx->d_small + CNT_LYN_K,
-                                                                    ctx->d_small + CNT_LYN_OVF, LYN_WORK_CAP);
-        HIPC(hipGetLastError());
+    // resumable resolver: long comparisons are decided by a grid-wide kernel between two of its launches
+    LynState *d_st = (LynState *)(ctx->d_small + CNT_LYN_K);
+    LynState *h_st = (LynState *)(ctx->h_small + CNT_LYN_K);
+    unsigned long long *d_mis = (unsigned long long *)(ctx->d_small + CNT_LYN_K + 8);
+    HIPC(hipMemsetAsync(d_st, 0, sizeof(LynState), ctx->stream));
+    for (int iter = 0;; iter++) {
+        {
+            SpanGuard g(ctx, BWTS_K_LYNDON, cnt_c, 0);
+            lyndon_resolve_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(d_T, n, cand[res], cnt_c, fstart, d_st, LYN_WORK_CAP);
+            HIPC(hipGetLastError());
+        }
+        BWTS_TRY(read_small(ctx, CNT_LYN_K, 8));
+        if (h_st->status == 0) break;
+        if (h_st->status == 2 || iter > 4096) return BWTS_OK;       // too much sequential work: general path
+        // status 1: compare suffix(p) with suffix(cur) on the whole chip
+        u64 e = 0;
+        HIPC(hipMemcpyAsync(&e, cand[res] + h_st->next, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+        const u64 pp = e >> 1, qq = h_st->cur;
+        const u64 len = n - pp;
+        HIPC(hipMemcpyAsync(d_mis, &len, sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        {
+            SpanGuard g(ctx, BWTS_K_LYNDON, len, 2 * len);
+            u64 blocks = (len + 255) / 256; if (blocks > 4096) blocks = 4096;
+            suffix_mismatch_grid_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(d_T, n, pp, qq, d_mis);
+            HIPC(hipGetLastError());
+        }
+        BWTS_TRY(read_small(ctx, CNT_LYN_K + 8, 1));
+        const u64 at = ctx->h_small[CNT_LYN_K + 8];
+        bool less;
+        if (at >= len) less = true;                                 // suffix(p) is a proper prefix of suffix(cur): the shorter is smaller
+        else {
+            u8 ab[2];
+            HIPC(hipMemcpyAsync(&ab[0], d_T + pp + at, 1, hipMemcpyDeviceToHost, ctx->stream));
+            HIPC(hipMemcpyAsync(&ab[1], d_T + qq + at, 1, hipMemcpyDeviceToHost, ctx->stream));
+            HIPC(hipStreamSynchronize(ctx->stream));
+            less = ab[0] < ab[1];
+        }
+        h_st->forced = 1; h_st->forced_less = less ? 1 : 0; h_st->status = 0;
+        HIPC(hipMemcpyAsync(d_st, h_st, sizeof(LynState), hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
     }
-    BWTS_TRY(read_small(ctx, CNT_LYN_K, 2));
-    if (ctx->h_small[CNT_LYN_OVF]) return BWTS_OK;
-    *k_out = ctx->h_small[CNT_LYN_K];
+    *k_out = h_st->k;
     if (*k_out == 0) return BWTS_E_INTERNAL;
     *done = true;
     return BWTS_OK;
