@@ -28,13 +28,12 @@ __device__ __forceinline__ u64 rx_tile_of_block(u64 tiles)
 }
 static inline u64 rx_grid(u64 tiles) { return (tiles + RX_XCDS - 1) / RX_XCDS * RX_XCDS; }
 
-// tile shapes compiled in; BWTS_RX_CONFIG picks one at first use (tuning knob)
-struct RxConfig { int threads, items, variant; };   // variant 1: keys and values staged one after the other (half the LDS)
-static const RxConfig kRxConfigs[] = {{256, 16, 0}, {512, 8, 0}, {512, 12, 0}, {1024, 4, 0}, {256, 12, 0}, {1024, 8, 0}, {512, 16, 0},
-                                      {1024, 6, 0}, {512, 16, 1}, {1024, 8, 1}, {256, 16, 1}, {512, 12, 1}, {256, 32, 1}, {512, 20, 1},
-                                      {1024, 16, 1}, {1024, 12, 1}};
+// tile shapes compiled in; BWTS_RX_CONFIG picks one at first use (tuning knob).  Shape 0 is the product shape:
+// 512 threads x 16 items = 8192 elements, two tiles resident per CU; only it carries the byte stream.
+struct RxConfig { int threads, items; };
+static const RxConfig kRxConfigs[] = {{512, 16}, {512, 12}, {256, 16}, {1024, 8}};
 #define RX_NCONFIGS ((int)(sizeof(kRxConfigs) / sizeof(kRxConfigs[0])))
-#define RX_DEFAULT_CONFIG 8
+#define RX_DEFAULT_CONFIG 0
 
 static int rx_config_index(void)
 {
@@ -137,105 +136,7 @@ __global__ __launch_bounds__(256) void radix_chunk_apply_kernel(u32 *__restrict_
     }
 }
 
-template <int RX_THREADS, int RX_ITEMS>
-__global__ __launch_bounds__(RX_THREADS) void radix_scatter_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
-                                                                    u64 *__restrict__ kout, u32 *__restrict__ vout,
-                                                                    const u32 *__restrict__ tile_off, u64 m, int shift)
-{
-    constexpr int RX_WAVES = RX_THREADS / 64;
-    constexpr int RX_TILE = RX_THREADS * RX_ITEMS;
-    extern __shared__ __attribute__((aligned(16))) char rx_smem[];
-    u64 *skeys = (u64 *)rx_smem;                                  // RX_TILE
-    u32 *svals = (u32 *)(skeys + RX_TILE);                        // RX_TILE
-    u32 (*whist)[256] = (u32 (*)[256])(svals + RX_TILE);          // RX_WAVES x 256
-    u32 *dbase = (u32 *)(whist + RX_WAVES);                       // 256
-    u32 *gbase = dbase + 256;                                     // 256
-    u32 *scan_sm = gbase + 256;                                   // RX_WAVES
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const u64 tile = rx_tile_of_block((m + RX_TILE - 1) / RX_TILE);
-    const u64 tile_base = tile * RX_TILE;
-    if (tile_base >= m) return;                                   // padding block of the XCD-aligned grid
-    const u64 wave_base = tile_base + (u64)w * (64 * RX_ITEMS);
-    const u64 remain = m - tile_base;
-    const u32 tile_count = remain < RX_TILE ? (u32)remain : (u32)RX_TILE;
-
-    for (int i = tid; i < RX_WAVES * 256; i += RX_THREADS) ((u32 *)whist)[i] = 0;
-
-    u64 key[RX_ITEMS];
-    u32 val[RX_ITEMS];
-    u32 rnk[RX_ITEMS];
-#pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const u64 i = wave_base + (u64)j * 64 + lane;
-        const bool valid = i < m;
-        key[j] = valid ? kin[i] : ~0ull;
-        val[j] = valid ? vin[i] : 0u;
-    }
-    __syncthreads();
-
-    // stable rank of every element among equal digits of its wave (element order = (j, lane))
-#pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const bool valid = wave_base + (u64)j * 64 + lane < m;
-        const u32 d = (u32)(key[j] >> shift) & 255u;
-        const u64 peers = match_digit8(d, valid);
-        const u32 before = (u32)__popcll(peers & lanemask_lt());
-        const u32 cnt = (u32)__popcll(peers);
-        const u32 prev = whist[w][d];
-        rnk[j] = prev + before;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (valid && before == 0) whist[w][d] = prev + cnt;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-    __syncthreads();
-
-    // per digit: exclusive offsets across waves, then across digits (threads 0..255 own a digit)
-    {
-        u32 run = 0;
-        if (tid < 256) {
-#pragma unroll
-            for (int ww = 0; ww < RX_WAVES; ww++) {
-                const u32 c = whist[ww][tid];
-                whist[ww][tid] = run;
-                run += c;
-            }
-        }
-        u32 total;
-        const u32 exc = block_scan_exclusive<u32, OpAdd, RX_WAVES>(run, OpAdd(), 0u, scan_sm, &total);
-        if (tid < 256) {
-            dbase[tid] = exc;
-            gbase[tid] = tile_off[tile * 256 + tid] - exc;
-        }
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const bool valid = wave_base + (u64)j * 64 + lane < m;
-        if (valid) {
-            const u32 d = (u32)(key[j] >> shift) & 255u;
-            const u32 pos = dbase[d] + whist[w][d] + rnk[j];
-            skeys[pos] = key[j];
-            svals[pos] = val[j];
-        }
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const u32 s = (u32)j * RX_THREADS + tid;
-        if (s < tile_count) {
-            const u64 k = skeys[s];
-            const u32 d = (u32)(k >> shift) & 255u;
-            const u32 dst = gbase[d] + s;
-            kout[dst] = k;
-            vout[dst] = svals[s];
-        }
-    }
-}
-
-// Variant 1: the LDS tile holds the keys first and is then reused for the values (and, optionally, a third
+// The LDS tile holds the keys first and is then reused for the values (and, optionally, a third
 // one-byte stream), the per-wave digit counters are 16-bit and each slot's digit is kept in a byte table, so
 // the destination of a slot is re-derived instead of living in a register: 9 B of LDS per element instead
 // of 12, two 8192-element tiles fit a CU and one tile's loads overlap the other's ranking.
@@ -381,20 +282,6 @@ static void launch_hist_t(bwts_ctx *ctx, u64 tiles, const u64 *keys, u64 m, int 
     radix_hist_kernel<TH, IT><<<dim3((unsigned)tiles), dim3(TH), 0, ctx->stream>>>(keys, m, shift, tile_hist);
 }
 
-template <int TH, int IT>
-static int launch_scatter_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *tile_off,
-                            u64 m, int shift)
-{
-    constexpr size_t lds = (size_t)TH * IT * 12 + (size_t)(TH / 64) * 1024 + 2048 + (size_t)(TH / 64) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPC(hipFuncSetAttribute((const void *)radix_scatter_kernel<TH, IT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    radix_scatter_kernel<TH, IT><<<dim3((unsigned)rx_grid(tiles)), dim3(TH), lds, ctx->stream>>>(kin, vin, kout, vout, tile_off, m, shift);
-    return BWTS_OK;
-}
-
 template <int TH, int IT, int MINW, bool HAS_SYM = false, bool IDENT = false>
 static int launch_scatter2_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32 *vin, u64 *kout, u32 *vout, const u32 *tile_off,
                              u64 m, int shift, const u8 *sin = nullptr, u8 *sout = nullptr)
@@ -412,22 +299,10 @@ static int launch_scatter2_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32
 static void launch_hist(bwts_ctx *ctx, int cfg, u64 tiles, const u64 *keys, u64 m, int shift, u32 *tile_hist)
 {
     switch (cfg) {
-    case 0: launch_hist_t<256, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 1: launch_hist_t<512, 8>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 2: launch_hist_t<512, 12>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 3: launch_hist_t<1024, 4>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 4: launch_hist_t<256, 12>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 5: launch_hist_t<1024, 8>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 6: launch_hist_t<512, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 7: launch_hist_t<1024, 6>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 8: launch_hist_t<512, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 9: launch_hist_t<1024, 8>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 10: launch_hist_t<256, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 11: launch_hist_t<512, 12>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 12: launch_hist_t<256, 32>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 13: launch_hist_t<512, 20>(ctx, tiles, keys, m, shift, tile_hist); break;
-    case 14: launch_hist_t<1024, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
-    default: launch_hist_t<1024, 12>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 0: launch_hist_t<512, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 1: launch_hist_t<512, 12>(ctx, tiles, keys, m, shift, tile_hist); break;
+    case 2: launch_hist_t<256, 16>(ctx, tiles, keys, m, shift, tile_hist); break;
+    default: launch_hist_t<1024, 8>(ctx, tiles, keys, m, shift, tile_hist); break;
     }
 }
 
@@ -435,22 +310,10 @@ static int launch_scatter(bwts_ctx *ctx, int cfg, u64 tiles, const u64 *kin, con
                           const u32 *tile_off, u64 m, int shift)
 {
     switch (cfg) {
-    case 0: return launch_scatter_t<256, 16>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 1: return launch_scatter_t<512, 8>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 2: return launch_scatter_t<512, 12>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 3: return launch_scatter_t<1024, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 4: return launch_scatter_t<256, 12>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 5: return launch_scatter_t<1024, 8>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 6: return launch_scatter_t<512, 16>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 7: return launch_scatter_t<1024, 6>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 8: return launch_scatter2_t<512, 16, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 9: return launch_scatter2_t<1024, 8, 8>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 10: return launch_scatter2_t<256, 16, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 11: return launch_scatter2_t<512, 12, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 12: return launch_scatter2_t<256, 32, 2>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 13: return launch_scatter2_t<512, 20, 2>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    case 14: return launch_scatter2_t<1024, 16, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
-    default: return launch_scatter2_t<1024, 12, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 0: return launch_scatter2_t<512, 16, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 1: return launch_scatter2_t<512, 12, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    case 2: return launch_scatter2_t<256, 16, 4>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
+    default: return launch_scatter2_t<1024, 8, 8>(ctx, tiles, kin, vin, kout, vout, tile_off, m, shift);
     }
 }
 
@@ -467,7 +330,7 @@ int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp)
     return BWTS_OK;
 }
 
-bool radix_supports_sym(void) { return rx_config_index() == 8; }
+bool radix_supports_sym(void) { return rx_config_index() == 0; }
 
 int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, int *result_buf)
 {
@@ -492,7 +355,7 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
         }
         const bool ident = plan.vals_identity && p == 0;
         if (plan.sym_src) {
-            if (cfg != 8) return BWTS_E_INTERNAL;
+            if (cfg != 0) return BWTS_E_INTERNAL;
             const u8 *sin = p == 0 ? plan.sym_src : plan.sym_buf[(p - 1) & 1];
             u8 *sout = p == passes - 1 ? plan.sym_final : plan.sym_buf[p & 1];
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (ident ? 22 : 26) * m);
@@ -506,7 +369,7 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
                                                                       plan.vals[cur ^ 1], tile_hist, m, shift, sin, sout)));
             }
         } else if (ident) {
-            if (cfg != 8) return BWTS_E_INTERNAL;
+            if (cfg != 0) return BWTS_E_INTERNAL;
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 20 * m);
             BWTS_TRY((launch_scatter2_t<512, 16, 4, false, true>(ctx, tiles, plan.keys[cur], plan.vals[cur], plan.keys[cur ^ 1], plan.vals[cur ^ 1],
                                                                   tile_hist, m, shift)));

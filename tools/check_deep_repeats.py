@@ -1,6 +1,6 @@
 """Manual check (GPU box): inputs with long repeats -> many doubling rounds with a large tied set."""
 import os, sys, time, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import oracle_lib as O
 import __graft_entry__ as ge

@@ -1,7 +1,7 @@
 """BASELINE config 4 on the GPU box: dna(n = 2^32, seed 1).  The reference cannot run this input (32-bit
 indices), so parity is by properties: round trip = identity, byte histogram preserved, bwts[0] = T[n-1]."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()

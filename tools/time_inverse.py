@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package(); ctx = pkg.Context(0)
 n = 1 << 30

@@ -1,6 +1,6 @@
 """Manual tuning helper (GPU box): times the LSD passes for the tile shape selected by BWTS_RX_CONFIG."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import __graft_entry__ as ge
 pkg = ge.load_package()
