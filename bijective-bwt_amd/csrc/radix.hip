@@ -209,13 +209,29 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
     }
     __syncthreads();
 
+    // From here on every loop is split into "all LDS reads", then "all dependent work": inside one loop body the
+    // compiler keeps a read, its s_waitcnt and the dependent LDS/global operation together, which serialises sixteen
+    // LDS round trips per phase (seen in the ISA); batched, a phase costs about one.
+#define POS_GET(j) (((j) & 1) ? posp[(j) >> 1] >> 16 : posp[(j) >> 1] & 0xffffu)
+#define POS_SET(j, v) do { if ((j) & 1) posp[(j) >> 1] = (posp[(j) >> 1] & 0xffffu) | ((v) << 16); \
+                           else posp[(j) >> 1] = (posp[(j) >> 1] & 0xffff0000u) | (v); } while (0)
+    constexpr int HB = RX_ITEMS % 8 == 0 ? 8 : 4;                  // LDS reads batched per phase step
 #pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const bool valid = wave_base + (u64)j * 64 + lane < m;
-        const u32 d = (u32)(key[j] >> shift) & 255u;
-        const u32 p = ((j & 1) ? posp[j >> 1] >> 16 : posp[j >> 1] & 0xffffu) + dbase[d] + whist[w][d];
-        if (j & 1) posp[j >> 1] = (posp[j >> 1] & 0xffffu) | (p << 16); else posp[j >> 1] = (posp[j >> 1] & 0xffff0000u) | p;
-        if (valid) stage[p] = key[j];
+    for (int j0 = 0; j0 < RX_ITEMS; j0 += HB) {
+        u32 add[HB];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 d = (u32)(key[j0 + jj] >> shift) & 255u;
+            add[jj] = dbase[d] + whist[w][d];
+        }
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const int j = j0 + jj;
+            const bool valid = wave_base + (u64)j * 64 + lane < m;
+            const u32 p = POS_GET(j) + add[jj];
+            POS_SET(j, p);
+            if (valid) stage[p] = key[j];
+        }
     }
     // the keys' registers are free: the value (and byte) loads overlap the key write-out
     u32 val[RX_ITEMS];
@@ -236,13 +252,23 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const u32 s = (u32)j * RX_THREADS + tid;
-        if (s < tile_count) {
-            const u64 k = stage[s];
-            const u32 d = (u32)(k >> shift) & 255u;
-            sdig[s] = (u8)d;
-            kout[gbase[d] + s] = k;
+    for (int j0 = 0; j0 < RX_ITEMS; j0 += HB) {
+        u64 k[HB];
+        u32 g[HB];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 s = (u32)(j0 + jj) * RX_THREADS + tid;
+            k[jj] = s < tile_count ? stage[s] : 0ull;
+        }
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) g[jj] = gbase[(u32)(k[jj] >> shift) & 255u];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 s = (u32)(j0 + jj) * RX_THREADS + tid;
+            if (s < tile_count) {
+                sdig[s] = (u8)((u32)(k[jj] >> shift) & 255u);
+                kout[g[jj] + s] = k[jj];
+            }
         }
     }
     __syncthreads();
@@ -250,7 +276,7 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const bool valid = wave_base + (u64)j * 64 + lane < m;
-        const u32 p = (j & 1) ? posp[j >> 1] >> 16 : posp[j >> 1] & 0xffffu;
+        const u32 p = POS_GET(j);
         if (valid) {
             if (HAS_SYM) stage[p] = (u64)val[j] | ((u64)sym[j] << 32);
             else ((u32 *)stage)[p] = val[j];
@@ -258,19 +284,31 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const u32 s = (u32)j * RX_THREADS + tid;
-        if (s < tile_count) {
-            const u32 dst = gbase[sdig[s]] + s;
-            if (HAS_SYM) {
-                const u64 e = stage[s];
-                vout[dst] = (u32)e;
-                sout[dst] = (u8)(e >> 32);
-            } else {
-                vout[dst] = ((u32 *)stage)[s];
+    for (int j0 = 0; j0 < RX_ITEMS; j0 += HB) {
+        u64 e[HAS_SYM ? HB : 1];
+        u32 v32[HAS_SYM ? 1 : HB];
+        u32 g[HB];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 s = (u32)(j0 + jj) * RX_THREADS + tid;
+            const u32 sc = s < tile_count ? s : 0u;
+            if (HAS_SYM) e[jj] = stage[sc]; else v32[jj] = ((u32 *)stage)[sc];
+            g[jj] = sdig[sc];
+        }
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) g[jj] = gbase[g[jj]];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 s = (u32)(j0 + jj) * RX_THREADS + tid;
+            if (s < tile_count) {
+                const u32 dst = g[jj] + s;
+                if (HAS_SYM) { vout[dst] = (u32)e[jj]; sout[dst] = (u8)(e[jj] >> 32); }
+                else vout[dst] = v32[jj];
             }
         }
     }
+#undef POS_GET
+#undef POS_SET
 }
 
 // ------------------------------------------------------------------------------------
