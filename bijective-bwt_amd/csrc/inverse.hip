@@ -23,8 +23,7 @@
 #define LF_WAVES   4
 #define LF_ITEMS   16
 #define LF_TILE    (LF_THREADS * LF_ITEMS)
-#define LF_TOP     0x80000000u
-#define LF_MASK    0x7fffffffu
+#define LF_VISITED 0xffffffffu     // written over an entry once the walk has read it (LF is chased exactly once)
 
 
 #define SMI_HIST     0
@@ -117,8 +116,8 @@ __device__ __forceinline__ u32 symbol_of(const u64 *Ctab, u32 y)
     return lo;
 }
 
-// A lane walks LF from its splitter to the next one.  Along the way it marks the entries it visits (top
-// bit of LF, or a byte map when n >= 2^31), keeps the smallest index seen, and records the symbols it passes -- B[x] read off LF[x] -- into
+// A lane walks LF from its splitter to the next one.  Along the way it marks the entries it visits (it
+// overwrites them with LF_VISITED; a byte map is used instead when that value could be a real entry), keeps the smallest index seen, and records the symbols it passes -- B[x] read off LF[x] -- into
 // its node's slot of `seg`, 4 at a time.  A walk that reaches `slot` steps without meeting a splitter closes its
 // node there and continues as a fresh virtual node (ids >= s, handed out by an atomic counter), so no segment
 // outgrows its slot.  A wave pulls batches of splitter ids from a shared counter and hands them to its lanes as
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
         if (__ballot(have || !done) == 0) break;     // every lane has seen the counter run dry
         if (have) {
             const u32 y = LF[x];
-            if (BYTEMARK) marks[x] = 1; else LF[x] = y | LF_TOP;      // n >= 2^31 needs all 32 bits of LF: marks live in a byte map
+            if (BYTEMARK) marks[x] = 1; else LF[x] = LF_VISITED;      // the entry is not needed again; byte map only when 0xffffffff is a valid value
             {
                 const u32 sh = symbol_of(Ctab, y) << (8 * (len & 3u));
                 const u32 w = (len >> 2) & 3u;
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(256) void collect_unvisited_kernel(const u32 *__res
         u32 v = 0;
         if (i < n) {
             if (BYTEMARK) { un = marks[i] == 0; if (un) v = LF[i]; }
-            else { v = LF[i]; un = !(v & LF_TOP); }
+            else { v = LF[i]; un = v != LF_VISITED; }
         }
         const u64 m = __ballot(un);
         if (m) {
@@ -369,9 +368,10 @@ static int grid1(u64 m) { return (int)((m + 255) / 256); }
 
 // One attempt with splitter spacing 2^g.  *retry is set when more elements sit in splitter-free cycles than
 // the sweep collects; the caller then repeats with g = 0 (every element a splitter: plain pointer jumping).
-static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int g, bool *retry)
+static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int g, bool bytemark, bool *retry, bool *ambiguous)
 {
     *retry = false;
+    *ambiguous = false;
     const u64 G = 1ull << g;
     const u64 s = (n + G - 1) / G;
     const u64 tiles = (n + LF_TILE - 1) / LF_TILE;
@@ -390,7 +390,6 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     for (int i = 0; i < 20; i++) node[i] = arena_array<u32>(ctx, node_cap);
     CycleRec *d_recs = (CycleRec *)arena_alloc(ctx, node_cap * sizeof(CycleRec));
     u8 *seg = arena_array<u8>(ctx, node_cap * slot);
-    const bool bytemark = n >= 0x80000000ull || getenv("BWTS_BYTEMARK") != nullptr;   // LF values need bit 31 (env: test hook)
     u8 *marks = bytemark ? arena_array<u8>(ctx, n) : nullptr;
     if (!LF || !tile_hist || !scan_temp || !node[19] || !d_recs || !seg || (bytemark && !marks)) return BWTS_E_NOMEM;
     if (bytemark) HIPC(hipMemsetAsync(marks, 0, n, ctx->stream));
@@ -518,7 +517,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
                 u_cyc[at] = cid; u_t[at] = t++;
                 const u32 nx = h_ulf[at];
                 const auto it = std::lower_bound(h_uidx.begin(), h_uidx.end(), nx);
-                if (it == h_uidx.end() || *it != nx) return BWTS_E_INTERNAL;
+                if (it == h_uidx.end() || *it != nx) {
+                    if (!bytemark && n == 0x100000000ull) { *ambiguous = true; return BWTS_OK; }   // see the length check below
+                    return BWTS_E_INTERNAL;
+                }
                 at = (u64)(it - h_uidx.begin());
             } while (at != q);
             cycles.push_back(Cyc{h_uidx[q], t, LR_NIL});
@@ -538,7 +540,11 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
             used += cycles[c].len;
             if (cycles[c].leader != LR_NIL) { h_lidx.push_back(cycles[c].leader); h_lend.push_back(cyc_end[c]); }
         }
-        if (used != n) return BWTS_E_INTERNAL;
+        if (used != n) {
+            // n = 2^32 only: the one entry whose value equals LF_VISITED sat in a splitter-free cycle and was taken for visited
+            if (!bytemark && n == 0x100000000ull) { *ambiguous = true; return BWTS_OK; }
+            return BWTS_E_INTERNAL;
+        }
     }
     HIPC(hipMemcpyAsync(tmp_idx, h_lidx.data(), kc * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPC(hipMemcpyAsync(tmp_val, h_lend.data(), kc * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -584,11 +590,17 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
 int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
     if (n > 0x100000000ull) return BWTS_E_RANGE;
-    bool retry = false;
-    BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), &retry));
+    bool retry = false, ambiguous = false;
+    bool bytemark = getenv("BWTS_BYTEMARK") != nullptr;      // test hook; otherwise only after an ambiguous first attempt
+    BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), bytemark, &retry, &ambiguous));
+    if (ambiguous) {
+        bytemark = true;
+        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), bytemark, &retry, &ambiguous));
+    }
     if (retry) {
-        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, &retry));
-        if (retry) return BWTS_E_INTERNAL;
+        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, bytemark, &retry, &ambiguous));
+        if (ambiguous) BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, true, &retry, &ambiguous));
+        if (retry || ambiguous) return BWTS_E_INTERNAL;
     }
     return BWTS_OK;
 }
