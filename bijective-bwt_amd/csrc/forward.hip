@@ -918,9 +918,25 @@ int lyndon_factors_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u32 **d_fstart, u
 // ------------------------------------------------------------------------------------
 // emission (mk_bwts_sa.c:172-188): P[p] = T[cprev(p)], bwts[r] = P[sa[r]]
 // ------------------------------------------------------------------------------------
+// P[i] = T[i-1] (P[0] = T[n-1]); 16 bytes per thread: one 16-byte load, the byte in front of it, one 16-byte store
 __global__ __launch_bounds__(256) void prevsym_kernel(const u8 *__restrict__ T, u64 n, u8 *__restrict__ P)
 {
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) P[i] = i ? T[i - 1] : T[n - 1];
+    const bool vec_ok = (((uintptr_t)T | (uintptr_t)P) & 15) == 0;
+    for (u64 c = (u64)blockIdx.x * 256 + threadIdx.x; c * 16 < n; c += (u64)gridDim.x * 256) {
+        const u64 i = c * 16;
+        if (vec_ok && i + 16 <= n) {
+            const uint4 v = *(const uint4 *)(T + i);
+            const u32 before = i ? (u32)T[i - 1] : (u32)T[n - 1];
+            uint4 o;
+            o.x = (v.x << 8) | before;
+            o.y = (v.y << 8) | (v.x >> 24);
+            o.z = (v.z << 8) | (v.y >> 24);
+            o.w = (v.w << 8) | (v.z >> 24);
+            *(uint4 *)(P + i) = o;
+        } else {
+            for (u64 j = i; j < n && j < i + 16; j++) P[j] = j ? T[j - 1] : T[n - 1];
+        }
+    }
 }
 __global__ __launch_bounds__(256) void prevsym_fix_kernel(const u8 *__restrict__ T, u64 n, const u32 *__restrict__ fstart, u64 k,
                                                           u8 *__restrict__ P)
@@ -981,7 +997,7 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     if (!P) return BWTS_E_NOMEM;
     {
         SpanGuard g(ctx, BWTS_K_OTHER, n, 2 * n);
-        u64 blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+        u64 blocks = (n / 16 + 255) / 256 + 1; if (blocks > 8192) blocks = 8192;
         prevsym_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(d_in, n, P);
         prevsym_fix_kernel<<<dim3((unsigned)((k + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_in, n, d_fstart, k, P);
         HIPC(hipGetLastError());
