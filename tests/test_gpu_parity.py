@@ -151,6 +151,24 @@ def test_inverse_many_tiny_cycles(ctx):
     assert np.array_equal(ctx.inverse(f), y)
 
 
+@pytest.mark.parametrize("off_in,off_out", [(1, 0), (3, 5), (0, 7), (13, 2)])
+def test_unaligned_device_pointers(ctx, off_in, off_out):
+    """Device entry points take any byte address (the vectorised kernels fall back when a pointer is not 16-byte aligned)."""
+    n = 300007
+    x = O.generate("zipf", n, 17)
+    want = O.forward(x)
+    d_a, d_b, d_c = ctx.alloc(n + 16), ctx.alloc(n + 16), ctx.alloc(n + 16)
+    try:
+        d_a.upload(np.concatenate([np.zeros(off_in, dtype=np.uint8), x]))
+        ctx.forward_device(d_a.ptr + off_in, n, d_b.ptr + off_out)
+        assert np.array_equal(d_b.download()[off_out:off_out + n], want)
+        ctx.inverse_device(d_b.ptr + off_out, n, d_c.ptr + off_in)
+        assert np.array_equal(d_c.download()[off_in:off_in + n], x)
+    finally:
+        for b in (d_a, d_b, d_c):
+            b.free()
+
+
 def test_errors(ctx, pkg):
     with pytest.raises(pkg.BwtsError) as e:
         ctx.forward(b"")
