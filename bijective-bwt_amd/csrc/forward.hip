@@ -37,9 +37,14 @@ struct Alphabet {
     int sigma;      // distinct byte values present
     int bits;       // bits per symbol code
     int msym;       // symbols packed into a round-0 key
-    int key_bits;   // bits * msym
+    int key_bits;   // bits * msym (fixed-width codes) or the chosen key width (variable-length codes)
     int pad_add;    // added to a table code by the kernels (9-bit padded alphabet only)
+    bool varlen;    // order-preserving variable-length codes (optimal alphabetic tree) instead of fixed-width ones
+    int hstep;      // symbols every key is guaranteed to cover: the step of round 1 (msym, or key_bits / longest code)
+    int patch_span; // positions in front of a factor's end whose key wraps around (msym - 1, or 64)
 };
+#define SM_VTAB 2048        // 256 words: (length << 32) | code of each byte value (variable-length codes)
+#define VL_MAXLEN 24        // longest code the variable-length key builder accepts
 
 static int bitlen_u64(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
 
@@ -115,6 +120,64 @@ static int pick_key_symbols(const u64 *hist, u64 n, int bits, int max_sym)
     return m;
 }
 
+// Optimal alphabetic (order-preserving prefix) code for the byte histogram: the classic interval DP with Knuth's
+// monotone-root bound, O(sigma^2).  Order-preserving means that comparing concatenated code words bit by bit is
+// comparing the symbol strings, so packed code bits sort like the text does -- but frequent symbols take fewer bits,
+// so a key of B bits separates positions about as well as B bits of entropy would.  Returns the longest code length.
+static int build_alphabetic_code(const u64 *hist, u64 n, u32 *code, u8 *len, double *avg_len, double *entropy)
+{
+    static double C[256][256];
+    static u16 R[256][256];
+    int sym[256], sigma = 0;
+    double w[256], pre[257];
+    for (int c = 0; c < 256; c++) { code[c] = 0; len[c] = 0; if (hist[c]) sym[sigma++] = c; }
+    const double smooth = (double)(n >> 14) + 1.0;          // keeps rare symbols' codes short enough for the key builder
+    pre[0] = 0;
+    for (int i = 0; i < sigma; i++) { w[i] = (double)hist[sym[i]] + smooth; pre[i + 1] = pre[i] + w[i]; }
+    if (sigma == 1) { len[sym[0]] = 1; *avg_len = 1; *entropy = 0; return 1; }
+    for (int i = 0; i < sigma; i++) { C[i][i] = 0; R[i][i] = (u16)i; }
+    for (int L = 2; L <= sigma; L++) {
+        for (int i = 0; i + L - 1 < sigma; i++) {
+            const int j = i + L - 1;
+            int lo = R[i][j - 1], hi = R[i + 1][j];
+            if (lo < i) lo = i;
+            if (hi > j - 1) hi = j - 1;
+            if (hi < lo) hi = lo;
+            double best = 1e300; int arg = lo;
+            for (int k = lo; k <= hi; k++) {
+                const double v = C[i][k] + C[k + 1][j];
+                if (v < best) { best = v; arg = k; }
+            }
+            C[i][j] = best + (pre[j + 1] - pre[i]);
+            R[i][j] = (u16)arg;
+        }
+    }
+    // walk the tree: left = 0, right = 1
+    struct Item { int i, j, depth; u32 prefix; } stack[512];
+    int sp = 0, lmax = 0;
+    stack[sp++] = Item{0, sigma - 1, 0, 0u};
+    while (sp) {
+        const Item it = stack[--sp];
+        if (it.i == it.j) {
+            len[sym[it.i]] = (u8)it.depth; code[sym[it.i]] = it.prefix;
+            if (it.depth > lmax) lmax = it.depth;
+            continue;
+        }
+        if (it.depth >= 31) return 99;
+        const int k = R[it.i][it.j];
+        stack[sp++] = Item{k + 1, it.j, it.depth + 1, (it.prefix << 1) | 1u};
+        stack[sp++] = Item{it.i, k, it.depth + 1, it.prefix << 1};
+    }
+    double al = 0, h = 0;
+    for (int i = 0; i < sigma; i++) {
+        const double p = (double)hist[sym[i]] / (double)n;
+        al += p * len[sym[i]];
+        h -= p * log2(p);
+    }
+    *avg_len = al; *entropy = h;
+    return lmax;
+}
+
 static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al)
 {
     u8 codes[256];
@@ -141,6 +204,37 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al)
     const char *env = getenv("BWTS_KEY_SYMBOLS");              // tuning / test knob: force the symbol count (0 = maximum)
     if (env) { int v = atoi(env); if (v >= 1 && v <= 64 / bits) al->msym = v; else if (v == 0) al->msym = 64 / bits; }
     al->key_bits = al->bits * al->msym;
+    al->varlen = false;
+    al->hstep = al->msym;
+    al->patch_span = al->msym - 1;
+    // variable-length codes when they save whole radix passes (skewed alphabets: text); the suffix sort of the general
+    // Lyndon path keeps fixed-width codes with the pad symbol
+    const char *vl = getenv("BWTS_VARLEN");                    // 0 = never, 1 = always (tests), unset = when it pays
+    if (!reserve_pad && sigma > 1 && !(vl && vl[0] == '0') && !(env && !vl)) {
+        u32 vcode[256]; u8 vlen[256];
+        double avg = 0, ent = 0;
+        const int lmax = build_alphabetic_code(ctx->h_small + SM_HIST, n, vcode, vlen, &avg, &ent);
+        if (lmax <= VL_MAXLEN) {
+            // bits wanted: as in pick_key_symbols, scaled by the code's redundancy (its bits are not perfectly fair coins)
+            const double redundancy = ent > 0.5 ? avg / ent : 1.0;
+            int kb = (int)ceil((log2((double)n) + 8.0) * redundancy * 1.10 / 8.0) * 8;
+            if (kb < 32) kb = 32;
+            if (kb > 64) kb = 64;
+            const char *kbe = getenv("BWTS_KEY_BITS");
+            if (kbe) { int v = atoi(kbe); if (v >= 8 && v <= 64) kb = v; }
+            const int passes_fixed = (al->key_bits + 7) / 8, passes_var = (kb + 7) / 8;
+            if ((vl && vl[0] == '1') || passes_var < passes_fixed) {
+                al->varlen = true;
+                al->key_bits = kb;
+                al->hstep = kb / lmax < 1 ? 1 : kb / lmax;
+                al->patch_span = 64;
+                al->msym = al->hstep;
+                u64 *tab = ctx->h_small + SM_VTAB;
+                for (int c = 0; c < 256; c++) tab[c] = ((u64)vlen[c] << 32) | vcode[c];
+                HIPC(hipMemcpyAsync(ctx->d_small + SM_VTAB, tab, 256 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            }
+        }
+    }
     memcpy(ctx->h_small + SM_CODES, codes, 256);
     HIPC(hipMemcpyAsync(ctx->d_small + SM_CODES, ctx->h_small + SM_CODES, 256, hipMemcpyHostToDevice, ctx->stream));
     HIPC(hipStreamSynchronize(ctx->stream));   // h_small is reused by later read-backs
@@ -245,6 +339,137 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
     }
 }
 
+// ---- variable-length codes -------------------------------------------------------------------------------------
+// key = the first key_bits bits of the concatenated code words starting at position q (right-aligned in the u64)
+__device__ __forceinline__ u64 vl_key_plain(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab, int key_bits, u64 q)
+{
+    u64 acc = 0;
+    int filled = 0;
+    while (filled < key_bits) {
+        if (q >= n) { acc <<= (key_bits - filled); break; }         // past the text: zero bits
+        const u64 e = vtab[T[q++]];
+        const int l = (int)(e >> 32), room = key_bits - filled;
+        const u64 c = (u32)e;
+        if (l <= room) { acc = (acc << l) | c; filled += l; }
+        else { acc = (acc << room) | (c >> (l - room)); filled = key_bits; }
+    }
+    return acc;
+}
+__device__ __forceinline__ u64 vl_key_cyclic(const u8 *__restrict__ T, const u64 *__restrict__ vtab, int key_bits, u64 q, u64 s, u64 e_)
+{
+    u64 acc = 0;
+    int filled = 0;
+    while (filled < key_bits) {
+        const u64 e = vtab[T[q]];
+        if (++q == e_) q = s;
+        const int l = (int)(e >> 32), room = key_bits - filled;
+        const u64 c = (u32)e;
+        if (l <= room) { acc = (acc << l) | c; filled += l; }
+        else { acc = (acc << room) | (c >> (l - room)); filled = key_bits; }
+    }
+    return acc;
+}
+
+// Round-0 keys from variable-length codes: the tile's code words are laid end to end as a bit stream in LDS
+// (bit offsets by a workgroup scan of the code lengths), and the key of a position is the key_bits-bit window
+// that starts at its offset.  Same outputs as keybuild0_kernel (keys, tile minima), same tile size.
+#define KV_ITEMS 9            // 256 threads x 9 >= 2048 + 64 symbols
+__global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab_g,
+                                                                int key_bits, u64 *__restrict__ keys, u64 *__restrict__ tile_min)
+{
+    __shared__ u64 vtab[256];
+    __shared__ __attribute__((aligned(16))) u8 sb[KB_THREADS * KV_ITEMS];
+    __shared__ u32 bitpos[KB_THREADS * KV_ITEMS];
+    __shared__ u32 stream[(KB_TILE + KB_HALO) * VL_MAXLEN / 32 + 8];
+    __shared__ u64 skey[KB_TILE + KB_TILE / 8];
+    __shared__ u32 scan_sm[KB_THREADS / 64];
+    __shared__ u64 wmin[KB_THREADS / 64];
+
+    const int tid = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * KB_TILE;
+    const u64 end = base + KB_TILE < n ? base + KB_TILE : n;
+    vtab[tid] = vtab_g[tid];
+    for (u32 i = tid; i < (KB_TILE + KB_HALO) * VL_MAXLEN / 32 + 8; i += KB_THREADS) stream[i] = 0;
+    const u32 span = KB_TILE + KB_HALO;
+    const u64 avail = n - base;                                 // symbols of the text from the tile's start
+    const u32 nvalid = avail < span ? (u32)avail : span;
+    const bool vec_ok = ((uintptr_t)T & 15) == 0;
+    for (u32 c = tid; c * 16 < span; c += KB_THREADS) {
+        const u64 q0 = base + (u64)c * 16;
+        if (vec_ok && q0 + 16 <= n) {
+            *(uint4 *)(sb + c * 16) = *(const uint4 *)(T + q0);
+        } else {
+            for (int bb = 0; bb < 16; bb++) sb[c * 16 + bb] = q0 + bb < n ? T[q0 + bb] : (u8)0;
+        }
+    }
+    __syncthreads();
+    // bit offset of every symbol of the tile and its halo
+    {
+        const u32 i0 = (u32)tid * KV_ITEMS;
+        u32 l[KV_ITEMS], sum = 0;
+#pragma unroll
+        for (int j = 0; j < KV_ITEMS; j++) {
+            l[j] = i0 + j < nvalid ? (u32)(vtab[sb[i0 + j]] >> 32) : 0u;
+            sum += l[j];
+        }
+        u32 total;
+        u32 run = block_scan_exclusive<u32, OpAdd, KB_THREADS / 64>(sum, OpAdd(), 0u, scan_sm, &total);
+#pragma unroll
+        for (int j = 0; j < KV_ITEMS; j++) {
+            bitpos[i0 + j] = run;
+            if (l[j]) {
+                // code word -> bits [run, run + l) of the stream, most significant bit first
+                const u64 v = ((u64)(u32)vtab[sb[i0 + j]] << (64 - l[j])) >> (run & 31u);
+                atomicOr(&stream[run >> 5], (u32)(v >> 32));
+                if ((u32)v) atomicOr(&stream[(run >> 5) + 1], (u32)v);
+            }
+            run += l[j];
+        }
+    }
+    __syncthreads();
+    const u32 o = (u32)tid * KB_ITEMS;
+    u64 lo = ~0ull;
+#pragma unroll
+    for (int e = 0; e < KB_ITEMS; e++) {
+        if (base + o + e < end) {
+            const u32 b = bitpos[o + e], w = b >> 5, sh = b & 31u;
+            const u64 hi = ((u64)stream[w] << 32) | stream[w + 1];
+            const u64 win = sh ? (hi << sh) | ((u64)stream[w + 2] >> (32 - sh)) : hi;
+            const u64 key = win >> (64 - key_bits);
+            skey[o + e + ((o + e) >> 3)] = key;
+            lo = key < lo ? key : lo;
+        }
+    }
+    if (tile_min) {
+        lo = wave_scan_inclusive(lo, OpMin());
+        if (lane_id() == 63) wmin[wave_id()] = lo;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KB_ITEMS; j++) {
+        const u32 e = (u32)j * KB_THREADS + tid;
+        if (base + e < end) keys[base + e] = skey[e + (e >> 3)];
+    }
+    if (tile_min && tid == 0) {
+        u64 t = wmin[0];
+        for (int w = 1; w < KB_THREADS / 64; w++) t = wmin[w] < t ? wmin[w] : t;
+        tile_min[blockIdx.x] = t;
+    }
+}
+
+// keys of the (up to 64) positions in front of each factor end wrap around inside the factor
+__global__ __launch_bounds__(256) void cyclic_patch_vl_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab, int key_bits,
+                                                              const u32 *__restrict__ fstart, u64 k, u64 *__restrict__ keys)
+{
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= k * 64) return;
+    const u64 f = t / 64, j = t % 64;
+    const u64 s = fstart[f], e = factor_end(fstart, k, n, f);
+    if (j >= e - s) return;
+    const u64 p = e - 1 - j;
+    keys[p] = vl_key_cyclic(T, vtab, key_bits, p, s, e);
+}
+
 __global__ __launch_bounds__(256) void iota_kernel(u32 *__restrict__ v, u64 n)
 {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) v[i] = (u32)i;
@@ -287,7 +512,8 @@ template <bool CYCLIC>
 __global__ __launch_bounds__(256) void keybuild_lb_kernel(const u32 *__restrict__ a_idx, const u32 *__restrict__ a_head, u64 a,
                                                           const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes,
                                                           int bits, int msym, int pad_add, const u64 *__restrict__ K0, int rb,
-                                                          const u32 *__restrict__ fstart, u64 k, u64 *__restrict__ keys)
+                                                          const u32 *__restrict__ fstart, u64 k, u64 *__restrict__ keys,
+                                                          const u64 *__restrict__ vtab /* variable-length codes, or null */, int key_bits)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= a) return;
@@ -297,8 +523,8 @@ __global__ __launch_bounds__(256) void keybuild_lb_kernel(const u32 *__restrict_
     if (CYCLIC) {
         const u64 f = factor_of(fstart, k, p);
         const u64 s = fstart[f], e = factor_end(fstart, k, n, f), L = e - s;
-        const u64 q = s + ((p - s) + (u64)msym % L) % L;
-        want = cyclic_key(T, codes, bits, msym, q, s, e);
+        const u64 q = s + ((p - s) + (u64)msym % L) % L;               // msym = the step: symbols every key surely covers
+        want = vtab ? vl_key_cyclic(T, vtab, key_bits, q, s, e) : cyclic_key(T, codes, bits, msym, q, s, e);
     } else {
         const u64 q = p + (u64)msym;
         past_end = q >= n;
@@ -562,14 +788,15 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         const int round_key_bits = 2 * rb > 1 ? 2 * rb : 1;
         int nxt = 0;
 
-        for (u64 h = (u64)al.msym;; h <<= 1) {
+        for (u64 h = (u64)al.hstep;; h <<= 1) {
             rounds++;
             {
                 SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 20 * a);
                 const unsigned blocks = (unsigned)((a + 255) / 256);
                 if (!rank_valid)
                     keybuild_lb_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
-                        cur.idx, cur.head, a, d_T, n, d_codes, al.bits, al.msym, al.pad_add, K0, rb, d_fstart, k, akeys[0]);
+                        cur.idx, cur.head, a, d_T, n, d_codes, al.bits, al.hstep, al.pad_add, K0, rb, d_fstart, k, akeys[0],
+                        al.varlen ? ctx->d_small + SM_VTAB : nullptr, al.key_bits);
                 else
                     keybuild_h_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
                         cur.idx, cur.head, a, sp.rank, n, h, rb, d_fstart, k, akeys[0]);
@@ -621,6 +848,12 @@ static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet 
 {
     SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + 8 * n);
     const u64 blocks = (n + KB_TILE - 1) / KB_TILE;
+    if (al.varlen) {
+        keybuild0v_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(d_T, n, ctx->d_small + SM_VTAB, al.key_bits,
+                                                                                        sp.keys[0], tile_min);
+        HIPC(hipGetLastError());
+        return BWTS_OK;
+    }
     keybuild0_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(
         d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, sp.keys[0], tile_min);
     HIPC(hipGetLastError());
@@ -719,7 +952,7 @@ struct CandOut {
         base = shfl_t((u64)base, leader);
         if (c) {
             const u64 at = base + (u64)__popcll(m & lanemask_lt());
-            const bool definite = i == 0 || (ki < min_before && i + (u64)msym <= n);
+            const bool definite = i == 0 || (ki < min_before && i + (u64)msym <= n);     // msym: symbols a key may reach over
             if (at < cap) cand[at] = (i << 1) | (definite ? 1ull : 0ull);
         }
     }
@@ -820,7 +1053,7 @@ static int lyndon_fast(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, 
         HIPC(hipMemcpyAsync(sp.scan_temp, tile_min, tiles * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
         BWTS_TRY((device_scan_partials<u64, OpMin>(ctx, tiles, OpMin(), ~0ull, sp.scan_temp)));
         KeyIn in{sp.keys[0]};
-        CandOut out{sp.keys[0], n, al.msym, cand[0], LYN_CAND_CAP, ctx->d_small + CNT_CAND};
+        CandOut out{sp.keys[0], n, al.varlen ? 64 : al.msym, cand[0], LYN_CAND_CAP, ctx->d_small + CNT_CAND};
         TileMayHoldCandidate filter{tile_min};
         BWTS_TRY((device_scan_final<false, u64>(ctx, n, in, out, OpMin(), ~0ull, sp.scan_temp, filter)));
     }
@@ -924,7 +1157,13 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
         BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, nullptr));
     }
     // wrap the keys of positions near their factor's end
-    if (al->msym > 1) {
+    if (al->varlen) {
+        SpanGuard g(ctx, BWTS_K_KEYBUILD, *k_out * 64, 0);
+        const u64 threads = *k_out * 64;
+        cyclic_patch_vl_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+            d_T, n, ctx->d_small + SM_VTAB, al->key_bits, *d_fstart, *k_out, sp.keys[0]);
+        HIPC(hipGetLastError());
+    } else if (al->msym > 1) {
         SpanGuard g(ctx, BWTS_K_KEYBUILD, *k_out * (u64)(al->msym - 1), 0);
         const u64 threads = *k_out * (u64)(al->msym - 1);
         cyclic_patch_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(
