@@ -215,11 +215,34 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al)
         double avg = 0, ent = 0;
         const int lmax = build_alphabetic_code(ctx->h_small + SM_HIST, n, vcode, vlen, &avg, &ent);
         if (lmax <= VL_MAXLEN) {
-            // bits wanted: as in pick_key_symbols, scaled by the code's redundancy (its bits are not perfectly fair coins)
-            const double redundancy = ent > 0.5 ? avg / ent : 1.0;
-            int kb = (int)ceil((log2((double)n) + 8.0) * redundancy * 1.10 / 8.0) * 8;
-            if (kb < 32) kb = 32;
-            if (kb > 64) kb = 64;
+            // Width: the smallest whole number of bytes B for which an i.i.d. source with this histogram leaves at most
+            // ~0.8 % of the positions tied.  share[b] = probability that two independent positions agree on the first b
+            // bits of their code streams: both start with the same symbol and agree on the rest, or their first code
+            // words are both longer than b bits and agree on those b bits.
+            int kb = 64;
+            {
+                double p[256], share[65];
+                for (int c = 0; c < 256; c++) p[c] = (double)ctx->h_small[SM_HIST + c] / (double)n;
+                share[0] = 1.0;
+                for (int b = 1; b <= 64; b++) {
+                    double s = 0.0;
+                    for (int c = 0; c < 256; c++)
+                        if (vlen[c] && vlen[c] <= b) s += p[c] * p[c] * share[b - vlen[c]];
+                    // code words longer than b bits that share their first b bits are neighbours in symbol order
+                    // (alphabetic and prefix-free), so the partial term is a sum of squared run masses
+                    double mass = 0.0; u32 cur = 0; bool open = false;
+                    for (int c = 0; c < 256; c++) {
+                        if (!vlen[c] || vlen[c] <= b) continue;
+                        const u32 pc = vcode[c] >> (vlen[c] - b);
+                        if (open && pc == cur) mass += p[c];
+                        else { s += mass * mass; mass = p[c]; cur = pc; open = true; }
+                    }
+                    s += mass * mass;
+                    share[b] = s;
+                }
+                for (int b = 32; b <= 64; b += 8)
+                    if ((double)n * share[b] <= 1.0 / 128.0) { kb = b; break; }
+            }
             const char *kbe = getenv("BWTS_KEY_BITS");
             if (kbe) { int v = atoi(kbe); if (v >= 8 && v <= 64) kb = v; }
             const int passes_fixed = (al->key_bits + 7) / 8, passes_var = (kb + 7) / 8;
@@ -505,42 +528,81 @@ __global__ __launch_bounds__(256) void cyclic_patch_kernel(const u8 *__restrict_
 // ------------------------------------------------------------------------------------
 // later rounds: key = (group head, rank of the h-th (cyclic) successor)
 // ------------------------------------------------------------------------------------
-// Round 1 (h = msym): the successor's round-0 rank is its group-head slot = the number of
-// sorted round-0 keys below its own key, found by binary search in the sorted key array, so
-// round 0 never scatters a rank array (n random 4-byte writes).
+// Sparse rank mode (few tied elements): no rank array exists.  The rank of a position that round 0 left alone is
+// its slot = the number of sorted round-0 keys below its own key (binary search in the sorted key array); the rank
+// of a position that round 0 left tied comes from a small map: tpos = those positions, sorted; trank = their current
+// ranks, refreshed by every round.  So round 0 never scatters ranks (n random 4-byte writes), and a third or fourth
+// round for a handful of stubborn ties costs a handful of binary searches, not an n-sized rank build.
+__device__ __forceinline__ u64 tied_find(const u32 *__restrict__ tpos, u64 a0, u32 q)
+{
+    u64 lo = 0, hi = a0;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (tpos[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    return (lo < a0 && tpos[lo] == q) ? lo : ~0ull;
+}
+
 template <bool CYCLIC>
-__global__ __launch_bounds__(256) void keybuild_lb_kernel(const u32 *__restrict__ a_idx, const u32 *__restrict__ a_head, u64 a,
-                                                          const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes,
-                                                          int bits, int msym, int pad_add, const u64 *__restrict__ K0, int rb,
-                                                          const u32 *__restrict__ fstart, u64 k, u64 *__restrict__ keys,
-                                                          const u64 *__restrict__ vtab /* variable-length codes, or null */, int key_bits)
+__global__ __launch_bounds__(256) void keybuild_sparse_kernel(const u32 *__restrict__ a_idx, const u32 *__restrict__ a_head, u64 a,
+                                                              const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes,
+                                                              int bits, int msym, int pad_add, u64 h, const u64 *__restrict__ K0, int rb,
+                                                              const u32 *__restrict__ fstart, u64 k, u64 *__restrict__ keys,
+                                                              const u64 *__restrict__ vtab /* variable-length codes, or null */, int key_bits,
+                                                              const u32 *__restrict__ tpos, const u32 *__restrict__ trank, u64 a0)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= a) return;
     const u64 p = a_idx[i];
-    u64 want;
+    u64 q, s = 0, e = 0;
     bool past_end = false;
     if (CYCLIC) {
         const u64 f = factor_of(fstart, k, p);
-        const u64 s = fstart[f], e = factor_end(fstart, k, n, f), L = e - s;
-        const u64 q = s + ((p - s) + (u64)msym % L) % L;               // msym = the step: symbols every key surely covers
-        want = vtab ? vl_key_cyclic(T, vtab, key_bits, q, s, e) : cyclic_key(T, codes, bits, msym, q, s, e);
+        s = fstart[f]; e = factor_end(fstart, k, n, f);
+        const u64 L = e - s;
+        q = s + ((p - s) + h % L) % L;
     } else {
-        const u64 q = p + (u64)msym;
+        q = p + h;
         past_end = q >= n;
-        want = 0;
-        for (int j = 0; j < msym; j++) {
-            const u64 r = q + j;
-            want = (want << bits) | (r < n ? (u64)codes[T[r]] + (u64)pad_add : 0ull);
+    }
+    u64 r = 0;
+    if (!past_end) {
+        const u64 j = tied_find(tpos, a0, (u32)q);
+        if (j != ~0ull) {
+            r = trank[j];
+        } else {
+            u64 want;
+            if (CYCLIC) {
+                want = vtab ? vl_key_cyclic(T, vtab, key_bits, q, s, e) : cyclic_key(T, codes, bits, msym, q, s, e);
+            } else {
+                want = 0;
+                for (int jj = 0; jj < msym; jj++) {
+                    const u64 rr = q + jj;
+                    want = (want << bits) | (rr < n ? (u64)codes[T[rr]] + (u64)pad_add : 0ull);
+                }
+            }
+            u64 lo = 0, hi = n;
+            while (lo < hi) {
+                const u64 mid = (lo + hi) >> 1;
+                if (K0[mid] < want) lo = mid + 1; else hi = mid;
+            }
+            r = lo;
         }
     }
-    u64 lo = 0, hi = n;
-    while (lo < hi) {
-        const u64 mid = (lo + hi) >> 1;
-        if (K0[mid] < want) lo = mid + 1; else hi = mid;
-    }
-    const u64 r2 = CYCLIC ? lo : (past_end ? 0ull : lo + 1ull);
+    const u64 r2 = CYCLIC ? r : (past_end ? 0ull : r + 1ull);
     keys[i] = ((u64)a_head[i] << rb) | r2;
+}
+
+// tied map construction: keys = positions (sorted by the radix sort), values = round-0 group heads
+__global__ __launch_bounds__(256) void tied_map_keys_kernel(const u32 *__restrict__ idx, u64 a, u64 *__restrict__ keys)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < a) keys[i] = idx[i];
+}
+__global__ __launch_bounds__(256) void tied_map_finish_kernel(const u64 *__restrict__ keys, u64 a, u32 *__restrict__ tpos)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < a) tpos[i] = (u32)keys[i];
 }
 
 template <bool CYCLIC>
@@ -622,7 +684,8 @@ struct GroupIn {
 
 struct GroupOut {
     const u32 *S; const u32 *V; u64 a; int rb;     // rb < 0: round 0 (no older groups)
-    u32 *rank;                                      // may be nullptr (ranks not materialised yet)
+    u32 *rank;                                      // dense rank array, or nullptr
+    const u32 *tpos; u32 *trank; u64 a0;            // sparse rank map (tied positions -> rank), or nullptr
     u32 *SA;
     u32 *n_idx, *n_slot, *n_head;
     u64 *cnt_active, *cnt_splits;
@@ -635,6 +698,7 @@ struct GroupOut {
         const u32 val = (keep || rank || S) ? V[i] : 0u;     // round 0 touches the suffix array only for tied elements
         const u32 slot = S ? S[i] : (u32)i;
         if (rank) rank[val] = head;
+        if (tpos) { const u64 j = tied_find(tpos, a0, val); if (j != ~0ull) trank[j] = head; }
         if (S) SA[slot] = val;
         if (keep) {
             const u32 dst = (u32)v - 1u;
@@ -750,7 +814,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     {
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
         GroupIn in{K0, nullptr, n, -1};
-        GroupOut out{nullptr, SA, n, -1, nullptr, SA, cur.idx, cur.slot, cur.head, cnt + 0, cnt + 1};
+        GroupOut out{nullptr, SA, n, -1, nullptr, nullptr, nullptr, 0, SA, cur.idx, cur.slot, cur.head, cnt + 0, cnt + 1};
         BWTS_TRY((device_scan<true, u64>(ctx, n, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
     }
     BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
@@ -767,7 +831,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         // aux: two key buffers, one value scratch, two list sets
         char *base = nullptr;
         const size_t e4 = align_up((size_t)a * 4, 256), e8 = align_up((size_t)a * 8, 256);
-        BWTS_TRY(aux_reserve(ctx, 2 * e8 + 7 * e4, &base));
+        BWTS_TRY(aux_reserve(ctx, 2 * e8 + 9 * e4, &base));
         u64 *akeys[2] = {(u64 *)base, (u64 *)(base + e8)};
         char *q = base + 2 * e8;
         u32 *scratch = (u32 *)q; q += e4;
@@ -779,24 +843,41 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         }
         const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
         if (2 * rb > 64) return BWTS_E_RANGE;
-        // the binary-search rank of round 1 costs ~log2 n dependent loads per tied element: worth it only while few
-        // elements are tied (n random writes saved); otherwise build the rank array now (real text ties most m-grams)
-        if (a > n / 32) {
+        const int round_key_bits = 2 * rb > 1 ? 2 * rb : 1;
+        int nxt = 0;
+        // few tied elements: sparse rank map; many (real text ties most m-grams): the dense rank array, built once now
+        const bool sparse = a <= n / 32;
+        u32 *tpos = nullptr, *trank = nullptr;
+        const u64 a0 = a;
+        if (sparse) {
+            SpanGuard g(ctx, BWTS_K_RERANK, a, 24 * a);
+            tpos = (u32 *)(base + 2 * e8 + 7 * e4);          // the last two arrays of the aux block
+            trank = (u32 *)(base + 2 * e8 + 8 * e4);
+            tied_map_keys_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(cur.idx, a, akeys[0]);
+            HIPC(hipMemcpyAsync(scratch, cur.head, a * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+            SortPlan mp;
+            mp.keys[0] = akeys[0]; mp.keys[1] = akeys[1];
+            mp.vals[0] = scratch; mp.vals[1] = trank;
+            mp.tile_hist = sp.tile_hist; mp.scan_temp = sp.scan_temp;
+            int mr = 0;
+            BWTS_TRY(radix_sort_pairs(ctx, mp, a, bitlen_u64(n - 1) > 0 ? bitlen_u64(n - 1) : 1, &mr));
+            tied_map_finish_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(akeys[mr], a, tpos);
+            if (mr == 0) HIPC(hipMemcpyAsync(trank, scratch, a * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+            HIPC(hipGetLastError());
+        } else {
             BWTS_TRY(build_ranks(ctx, SA, n, cur, a, sp.rank));
             rank_valid = true;
         }
-        const int round_key_bits = 2 * rb > 1 ? 2 * rb : 1;
-        int nxt = 0;
 
         for (u64 h = (u64)al.hstep;; h <<= 1) {
             rounds++;
             {
                 SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 20 * a);
                 const unsigned blocks = (unsigned)((a + 255) / 256);
-                if (!rank_valid)
-                    keybuild_lb_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
-                        cur.idx, cur.head, a, d_T, n, d_codes, al.bits, al.hstep, al.pad_add, K0, rb, d_fstart, k, akeys[0],
-                        al.varlen ? ctx->d_small + SM_VTAB : nullptr, al.key_bits);
+                if (sparse)
+                    keybuild_sparse_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
+                        cur.idx, cur.head, a, d_T, n, d_codes, al.bits, al.msym, al.pad_add, h, K0, rb, d_fstart, k, akeys[0],
+                        al.varlen ? ctx->d_small + SM_VTAB : nullptr, al.key_bits, tpos, trank, a0);
                 else
                     keybuild_h_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
                         cur.idx, cur.head, a, sp.rank, n, h, rb, d_fstart, k, akeys[0]);
@@ -815,7 +896,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             {
                 SpanGuard g(ctx, BWTS_K_RERANK, a, 24 * a);
                 GroupIn in{AK, cur.slot, a, rb};
-                GroupOut out{cur.slot, AV, a, rb, rank_valid ? sp.rank : nullptr, SA,
+                GroupOut out{cur.slot, AV, a, rb, sparse ? nullptr : sp.rank, tpos, trank, a0, SA,
                              sets[nxt].idx, sets[nxt].slot, sets[nxt].head, cnt + 0, cnt + 1};
                 BWTS_TRY((device_scan<true, u64>(ctx, a, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
             }
@@ -829,11 +910,6 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             if (CYCLIC && splits == 0) break;               // partition stable under doubling: equal infinite words
             if (!CYCLIC && h >= n) return BWTS_E_INTERNAL;  // suffixes are distinct; cannot happen
             if (rounds > 80) return BWTS_E_INTERNAL;
-            if (!rank_valid) {
-                // a third round is needed: materialise the rank array once, from the suffix array
-                BWTS_TRY(build_ranks(ctx, SA, n, cur, a, sp.rank));
-                rank_valid = true;
-            }
         }
     }
     if (want_ranks && !rank_valid) BWTS_TRY(build_ranks(ctx, SA, n, a ? cur : none, a, sp.rank));
