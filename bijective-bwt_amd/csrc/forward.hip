@@ -393,26 +393,26 @@ __device__ __forceinline__ u64 vl_key_cyclic(const u8 *__restrict__ T, const u64
     return acc;
 }
 
-// Round-0 keys from variable-length codes: the tile's code words are laid end to end as a bit stream in LDS
-// (bit offsets by a workgroup scan of the code lengths), and the key of a position is the key_bits-bit window
-// that starts at its offset.  Same outputs as keybuild0_kernel (keys, tile minima), same tile size.
-#define KV_ITEMS 9            // 256 threads x 9 >= 2048 + 64 symbols
+// Round-0 keys from variable-length codes.  A thread owns 8 consecutive positions and keeps a 128-bit reservoir of
+// the code stream that starts at its current position: code words are appended at the tail as needed, the key is the
+// reservoir's first key_bits bits, and moving to the next position shifts the first symbol's code word out.  Every
+// symbol is looked up once per thread that needs it; no scan, no atomics.  Same outputs as keybuild0_kernel.
 __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab_g,
                                                                 int key_bits, u64 *__restrict__ keys, u64 *__restrict__ tile_min)
 {
-    __shared__ u64 vtab[256];
-    __shared__ __attribute__((aligned(16))) u8 sb[KB_THREADS * KV_ITEMS];
-    __shared__ u32 bitpos[KB_THREADS * KV_ITEMS];
-    __shared__ u32 stream[(KB_TILE + KB_HALO) * VL_MAXLEN / 32 + 8];
+    __shared__ u32 vtab[256];                                   // (length << 24) | code word
+    __shared__ u32 cw[KB_TILE + KB_HALO + 16];                  // the same, per position of the tile and its halo
     __shared__ u64 skey[KB_TILE + KB_TILE / 8];
-    __shared__ u32 scan_sm[KB_THREADS / 64];
     __shared__ u64 wmin[KB_THREADS / 64];
 
     const int tid = threadIdx.x;
     const u64 base = (u64)blockIdx.x * KB_TILE;
     const u64 end = base + KB_TILE < n ? base + KB_TILE : n;
-    vtab[tid] = vtab_g[tid];
-    for (u32 i = tid; i < (KB_TILE + KB_HALO) * VL_MAXLEN / 32 + 8; i += KB_THREADS) stream[i] = 0;
+    {
+        const u64 ent = vtab_g[tid];
+        vtab[tid] = ((u32)(ent >> 32) << 24) | (u32)ent;        // code words are at most VL_MAXLEN = 24 bits
+    }
+    __syncthreads();
     const u32 span = KB_TILE + KB_HALO;
     const u64 avail = n - base;                                 // symbols of the text from the tile's start
     const u32 nvalid = avail < span ? (u32)avail : span;
@@ -420,47 +420,47 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
     for (u32 c = tid; c * 16 < span; c += KB_THREADS) {
         const u64 q0 = base + (u64)c * 16;
         if (vec_ok && q0 + 16 <= n) {
-            *(uint4 *)(sb + c * 16) = *(const uint4 *)(T + q0);
+            const uint4 v = *(const uint4 *)(T + q0);
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) cw[c * 16 + a * 4 + bb] = vtab[(w[a] >> (8 * bb)) & 255u];
         } else {
-            for (int bb = 0; bb < 16; bb++) sb[c * 16 + bb] = q0 + bb < n ? T[q0 + bb] : (u8)0;
-        }
-    }
-    __syncthreads();
-    // bit offset of every symbol of the tile and its halo
-    {
-        const u32 i0 = (u32)tid * KV_ITEMS;
-        u32 l[KV_ITEMS], sum = 0;
-#pragma unroll
-        for (int j = 0; j < KV_ITEMS; j++) {
-            l[j] = i0 + j < nvalid ? (u32)(vtab[sb[i0 + j]] >> 32) : 0u;
-            sum += l[j];
-        }
-        u32 total;
-        u32 run = block_scan_exclusive<u32, OpAdd, KB_THREADS / 64>(sum, OpAdd(), 0u, scan_sm, &total);
-#pragma unroll
-        for (int j = 0; j < KV_ITEMS; j++) {
-            bitpos[i0 + j] = run;
-            if (l[j]) {
-                // code word -> bits [run, run + l) of the stream, most significant bit first
-                const u64 v = ((u64)(u32)vtab[sb[i0 + j]] << (64 - l[j])) >> (run & 31u);
-                atomicOr(&stream[run >> 5], (u32)(v >> 32));
-                if ((u32)v) atomicOr(&stream[(run >> 5) + 1], (u32)v);
-            }
-            run += l[j];
+            for (int bb = 0; bb < 16; bb++) cw[c * 16 + bb] = q0 + bb < n ? vtab[T[q0 + bb]] : 0u;
         }
     }
     __syncthreads();
     const u32 o = (u32)tid * KB_ITEMS;
     u64 lo = ~0ull;
+    if (base + o < end) {
+        u64 rh = 0, rl = 0;          // reservoir: bits [0,64) in rh, [64,128) in rl, most significant first
+        int have = 0;                // valid bits in the reservoir
+        u32 nxt = o;                 // next symbol to append
 #pragma unroll
-    for (int e = 0; e < KB_ITEMS; e++) {
-        if (base + o + e < end) {
-            const u32 b = bitpos[o + e], w = b >> 5, sh = b & 31u;
-            const u64 hi = ((u64)stream[w] << 32) | stream[w + 1];
-            const u64 win = sh ? (hi << sh) | ((u64)stream[w + 2] >> (32 - sh)) : hi;
-            const u64 key = win >> (64 - key_bits);
-            skey[o + e + ((o + e) >> 3)] = key;
-            lo = key < lo ? key : lo;
+        for (int e = 0; e < KB_ITEMS; e++) {
+            if (base + o + e < end) {
+                // top up: a key needs key_bits <= 64 bits; appended words are at most VL_MAXLEN bits, so 128 suffice
+                while (have < 64 && nxt < nvalid) {
+                    const u32 ent = cw[nxt++];
+                    const int l = (int)(ent >> 24);
+                    const u64 c = ent & 0xffffffu;
+                    const int at = have;                        // first bit the word occupies
+                    if (at + l <= 64) rh |= c << (64 - at - l);
+                    else if (at >= 64) rl |= c << (128 - at - l);
+                    else { rh |= c >> (at + l - 64); rl |= c << (128 - at - l); }
+                    have += l;
+                }
+                const u64 key = rh >> (64 - key_bits);
+                skey[o + e + ((o + e) >> 3)] = key;
+                lo = key < lo ? key : lo;
+                // drop this position's symbol
+                const int l0 = (int)(cw[o + e] >> 24);
+                rh = (rh << l0) | (rl >> (64 - l0));
+                rl <<= l0;
+                have -= l0;
+                if (have < 0) have = 0;                         // past the end of the text: nothing left but zeros
+            }
         }
     }
     if (tile_min) {
