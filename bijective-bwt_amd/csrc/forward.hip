@@ -400,19 +400,15 @@ __device__ __forceinline__ u64 vl_key_cyclic(const u8 *__restrict__ T, const u64
 __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab_g,
                                                                 int key_bits, u64 *__restrict__ keys, u64 *__restrict__ tile_min)
 {
-    __shared__ u32 vtab[256];                                   // (length << 24) | code word
-    __shared__ u32 cw[KB_TILE + KB_HALO + 16];                  // the same, per position of the tile and its halo
+    __shared__ u64 vtab[256];
+    __shared__ __attribute__((aligned(16))) u8 sb[KB_TILE + KB_HALO + 16];
     __shared__ u64 skey[KB_TILE + KB_TILE / 8];
     __shared__ u64 wmin[KB_THREADS / 64];
 
     const int tid = threadIdx.x;
     const u64 base = (u64)blockIdx.x * KB_TILE;
     const u64 end = base + KB_TILE < n ? base + KB_TILE : n;
-    {
-        const u64 ent = vtab_g[tid];
-        vtab[tid] = ((u32)(ent >> 32) << 24) | (u32)ent;        // code words are at most VL_MAXLEN = 24 bits
-    }
-    __syncthreads();
+    vtab[tid] = vtab_g[tid];
     const u32 span = KB_TILE + KB_HALO;
     const u64 avail = n - base;                                 // symbols of the text from the tile's start
     const u32 nvalid = avail < span ? (u32)avail : span;
@@ -420,14 +416,9 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
     for (u32 c = tid; c * 16 < span; c += KB_THREADS) {
         const u64 q0 = base + (u64)c * 16;
         if (vec_ok && q0 + 16 <= n) {
-            const uint4 v = *(const uint4 *)(T + q0);
-            const u32 w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int bb = 0; bb < 4; bb++) cw[c * 16 + a * 4 + bb] = vtab[(w[a] >> (8 * bb)) & 255u];
+            *(uint4 *)(sb + c * 16) = *(const uint4 *)(T + q0);
         } else {
-            for (int bb = 0; bb < 16; bb++) cw[c * 16 + bb] = q0 + bb < n ? vtab[T[q0 + bb]] : 0u;
+            for (int bb = 0; bb < 16; bb++) sb[c * 16 + bb] = q0 + bb < n ? T[q0 + bb] : (u8)0;
         }
     }
     __syncthreads();
@@ -442,9 +433,9 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
             if (base + o + e < end) {
                 // top up: a key needs key_bits <= 64 bits; appended words are at most VL_MAXLEN bits, so 128 suffice
                 while (have < 64 && nxt < nvalid) {
-                    const u32 ent = cw[nxt++];
-                    const int l = (int)(ent >> 24);
-                    const u64 c = ent & 0xffffffu;
+                    const u64 ent = vtab[sb[nxt++]];
+                    const int l = (int)(ent >> 32);
+                    const u64 c = (u32)ent;
                     const int at = have;                        // first bit the word occupies
                     if (at + l <= 64) rh |= c << (64 - at - l);
                     else if (at >= 64) rl |= c << (128 - at - l);
@@ -455,7 +446,7 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
                 skey[o + e + ((o + e) >> 3)] = key;
                 lo = key < lo ? key : lo;
                 // drop this position's symbol
-                const int l0 = (int)(cw[o + e] >> 24);
+                const int l0 = (int)(vtab[sb[o + e]] >> 32);
                 rh = (rh << l0) | (rl >> (64 - l0));
                 rl <<= l0;
                 have -= l0;
