@@ -120,6 +120,13 @@ static int pick_key_symbols(const u64 *hist, u64 n, int bits, int max_sym)
     return m;
 }
 
+// scratch the key-width sampler may use (round-0 sort buffers, free at that point)
+struct SampleScratch { const u8 *T; u64 *k[2]; u32 *v[2]; u32 *tile_hist; void *scan_temp; };
+#define KEY_SAMPLES (1u << 17)
+#define CNT_SAMPLE (SM_COUNTERS + 16)      // 5 words: adjacent sample keys agreeing on their first 24/32/40/48/56 bits
+__global__ void sample_keys_kernel(const u8 *T, u64 n, const u64 *vtab, u32 samples, u64 *out);
+__global__ void count_prefix_matches_kernel(const u64 *keys, u32 samples, unsigned long long *counters);
+
 // Optimal alphabetic (order-preserving prefix) code for the byte histogram: the classic interval DP with Knuth's
 // monotone-root bound, O(sigma^2).  Order-preserving means that comparing concatenated code words bit by bit is
 // comparing the symbol strings, so packed code bits sort like the text does -- but frequent symbols take fewer bits,
@@ -178,7 +185,7 @@ static int build_alphabetic_code(const u64 *hist, u64 n, u32 *code, u8 *len, dou
     return lmax;
 }
 
-static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al)
+static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, const SampleScratch *ss = nullptr)
 {
     u8 codes[256];
     int sigma = 0;
@@ -242,11 +249,48 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al)
                 }
                 for (int b = 32; b <= 64; b += 8)
                     if ((double)n * share[b] <= 1.0 / 128.0) { kb = b; break; }
+                // The model knows nothing about repeated phrases.  Where the input is large enough to matter, sort the keys
+                // of 2^17 sampled positions and count neighbours that agree on their first B bits: if the sample shows
+                // clearly more ties than the model allows, take the empirical figure (real text wants the full 64 bits).
+                if (ss && n >= (1ull << 22)) {
+                    u64 *tab = ctx->h_small + SM_VTAB;
+                    for (int c = 0; c < 256; c++) tab[c] = ((u64)vlen[c] << 32) | vcode[c];
+                    HIPC(hipMemcpyAsync(ctx->d_small + SM_VTAB, tab, 256 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+                    HIPC(hipMemsetAsync(ctx->d_small + CNT_SAMPLE, 0, 8 * sizeof(u64), ctx->stream));
+                    SpanGuard g(ctx, BWTS_K_KEYBUILD, KEY_SAMPLES, 0);
+                    sample_keys_kernel<<<dim3(KEY_SAMPLES / 256), dim3(256), 0, ctx->stream>>>(ss->T, n, ctx->d_small + SM_VTAB, KEY_SAMPLES, ss->k[0]);
+                    SortPlan spn;
+                    spn.keys[0] = ss->k[0]; spn.keys[1] = ss->k[1];
+                    spn.vals[0] = ss->v[0]; spn.vals[1] = ss->v[1];
+                    spn.tile_hist = ss->tile_hist; spn.scan_temp = ss->scan_temp;
+                    int sres = 0;
+                    BWTS_TRY(radix_sort_pairs(ctx, spn, KEY_SAMPLES, 64, &sres));
+                    count_prefix_matches_kernel<<<dim3(KEY_SAMPLES / 256), dim3(256), 0, ctx->stream>>>(
+                        ss->k[sres], KEY_SAMPLES, (unsigned long long *)(ctx->d_small + CNT_SAMPLE));
+                    HIPC(hipGetLastError());
+                    BWTS_TRY(read_small(ctx, CNT_SAMPLE, 5));
+                    const double pairs = 0.5 * (double)KEY_SAMPLES * (double)KEY_SAMPLES;
+                    int kb_emp = 64;
+                    for (int b = 32, w = 1; b <= 56; b += 8, w++) {
+                        const double m = (double)ctx->h_small[CNT_SAMPLE + w];
+                        const double partners = m >= 8.0 ? (double)n * m / pairs : (double)n * share[b];   // few hits: trust the model
+                        if (1.0 - exp(-partners) <= 1.0 / 64.0) { kb_emp = b; break; }
+                    }
+                    if (kb_emp > kb) {
+                        kb = kb_emp;
+                        // the fixed-width alternative was sized by the same model: let it use every symbol that fits
+                        al->msym = 64 / bits;
+                        al->key_bits = al->bits * al->msym;
+                        al->hstep = al->msym;
+                        al->patch_span = al->msym - 1;
+                    }
+                }
             }
             const char *kbe = getenv("BWTS_KEY_BITS");
             if (kbe) { int v = atoi(kbe); if (v >= 8 && v <= 64) kb = v; }
             const int passes_fixed = (al->key_bits + 7) / 8, passes_var = (kb + 7) / 8;
-            if ((vl && vl[0] == '1') || passes_var < passes_fixed) {
+            // equal pass counts: the variable-length key still holds more symbols when its words are shorter on average
+            if ((vl && vl[0] == '1') || passes_var < passes_fixed || (passes_var == passes_fixed && avg < (double)bits - 0.25)) {
                 al->varlen = true;
                 al->key_bits = kb;
                 al->hstep = kb / lmax < 1 ? 1 : kb / lmax;
@@ -391,6 +435,28 @@ __device__ __forceinline__ u64 vl_key_cyclic(const u8 *__restrict__ T, const u64
         else { acc = (acc << room) | (c >> (l - room)); filled = key_bits; }
     }
     return acc;
+}
+
+__global__ __launch_bounds__(256) void sample_keys_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab, u32 samples,
+                                                          u64 *__restrict__ out)
+{
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= samples) return;
+    const u64 pos = (((u64)i * 0x9E3779B97F4A7C15ull) >> 11) % n;       // scattered, reproducible sample positions
+    out[i] = vl_key_plain(T, n, vtab, 64, pos);
+}
+__global__ __launch_bounds__(256) void count_prefix_matches_kernel(const u64 *__restrict__ keys, u32 samples,
+                                                                   unsigned long long *__restrict__ counters)
+{
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = i > 0 && i < samples;
+    const u64 a = ok ? keys[i] : 0, b = ok ? keys[i - 1] : ~0ull;
+#pragma unroll
+    for (int w = 0; w < 5; w++) {
+        const int bits = 24 + 8 * w;
+        const u64 m = __ballot(ok && (a >> (64 - bits)) == (b >> (64 - bits)));
+        if (m && lane_id() == 0) atomicAdd(&counters[w], (unsigned long long)__popcll(m));
+    }
 }
 
 // Round-0 keys from variable-length codes.  A thread owns 8 consecutive positions and keeps a 128-bit reservoir of
@@ -1212,7 +1278,8 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
     if (mode != 2) {
         u64 *tile_min = arena_array<u64>(ctx, scan_tiles(n) + 1);
         if (!tile_min) return BWTS_E_NOMEM;
-        BWTS_TRY(set_alphabet(ctx, false, n, al));
+        SampleScratch ss{d_T, {sp.keys[0], sp.keys[1]}, {sp.vals[0], sp.vals[1]}, sp.tile_hist, sp.scan_temp};
+        BWTS_TRY(set_alphabet(ctx, false, n, al, &ss));
         BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, tile_min));
         BWTS_TRY(lyndon_fast(ctx, d_T, n, *al, sp, tile_min, cand, cvals, fast_starts, k_out, &done));
         if (done) *d_fstart = fast_starts;
@@ -1220,7 +1287,8 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
     }
     if (!done) {
         BWTS_TRY(lyndon_general(ctx, d_T, n, sp, d_fstart, k_out, lyndon_rounds));
-        BWTS_TRY(set_alphabet(ctx, false, n, al));
+        SampleScratch ss{d_T, {sp.keys[0], sp.keys[1]}, {sp.vals[0], sp.vals[1]}, sp.tile_hist, sp.scan_temp};
+        BWTS_TRY(set_alphabet(ctx, false, n, al, &ss));
         BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, nullptr));
     }
     // wrap the keys of positions near their factor's end
