@@ -5,6 +5,7 @@ import hashlib
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -268,6 +269,25 @@ def test_cli_end_to_end(tmp_path):
     r = subprocess.run([os.path.join(PKG, "mk_bwts"), str(src), str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     labels = [l.split(" time ")[0] for l in r.stderr.decode().splitlines() if " time " in l]
     assert labels[:4] == ["Suffix sort", "Compute ISA", "Fix sort order", "Generate BWTS"]           # mk_bwts_sa.c:50,124,168,190
+
+
+# ---------------------------------------------------------------------------------------------
+# alternate code paths, selected by environment knobs (read once per process -> one child process per mode)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("env", [
+    {"BWTS_VARLEN": "1", "BWTS_KEY_BITS": "24"},      # variable-length key codes on every input, narrow keys: many ties, sparse ranks
+    {"BWTS_VARLEN": "1", "BWTS_KEY_BITS": "64"},
+    {"BWTS_VARLEN": "0", "BWTS_KEY_SYMBOLS": "2"},    # fixed-width keys of two symbols: nearly everything tied, dense ranks
+    {"BWTS_LYNDON": "general"},                       # factors from a full suffix sort + prefix minima of ISA
+    {"BWTS_EMIT": "gather"},                          # classic bwts[r] = P[sa[r]] gather instead of the carried byte
+    {"BWTS_BYTEMARK": "1"},                           # inverse marks in a byte map (the n = 2^32 fallback)
+    {"BWTS_SPLIT_LOG2": "0"},                         # inverse: every element a splitter (plain pointer jumping)
+], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_alternate_paths(env):
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+           "-k", "small or mid_size or deep_repeats or reference_unbwts_vectors_through_cabi"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env), cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
 
 
 def test_smoke_entry():
