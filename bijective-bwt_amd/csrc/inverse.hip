@@ -116,22 +116,45 @@ __device__ __forceinline__ u32 symbol_of(const u64 *Ctab, u32 y)
     return lo;
 }
 
-// A lane walks LF from its splitter to the next one.  Along the way it marks the entries it visits (it
-// overwrites them with LF_VISITED; a byte map is used instead when that value could be a real entry), keeps the smallest index seen, and records the symbols it passes -- B[x] read off LF[x] -- into
+// A lane walks LF from its splitter to the next one.  Along the way it leaves evidence of the entries it visits
+// (MARK below), keeps the smallest index seen, and records the symbols it passes -- B[x] read off LF[x] -- into
 // its node's slot of `seg`, 4 at a time.  A walk that reaches `slot` steps without meeting a splitter closes its
 // node there and continues as a fresh virtual node (ids >= s, handed out by an atomic counter), so no segment
 // outgrows its slot.  A wave pulls batches of splitter ids from a shared counter and hands them to its lanes as
 // they finish (one atomic per WALK_BATCH walks); every walk ends at the next splitter (LF is a permutation) and
 // a lane that finds the counter exhausted stops asking, so every wave drains.
+#ifndef WALK_BATCH
 #define WALK_BATCH 128
-template <bool BYTEMARK>
-__global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, u8 *__restrict__ marks, u64 s, u64 node_cap, int g, u32 slot,
+#endif
+// MARK: how the walk leaves evidence of the entries it visited, so that cycles without a splitter can be found:
+//   0  index log   -- every step the wave appends the indices its active lanes stand on to its own log chunk, back to
+//                     back (one contiguous store per wave and step; the log is a set, it does not say which node an
+//                     index belongs to).  The unvisited complement comes from bucket_indices_kernel +
+//                     unvisited_from_buckets_kernel.  The walk then costs one random line fill per step and nothing
+//                     else that is random: measured 58 -> 35 ms at n = 2^30 against sentinel marks.
+//   1  sentinel    -- the entry is overwritten with LF_VISITED (one extra random 32-byte write per step)
+//   2  byte map    -- marks[x] = 1 (when LF_VISITED could be a real entry: n = 2^32)
+// WALK_PROFILE (compile-time) stamps wall-clock times of first start / pool exhausted / wave ends into ticket[8..12]:
+// at n = 2^30 the pool runs dry at ~29 ms whatever the walker count (64 K .. 512 K lanes) and batch size, and the
+// longest residual chain (~G ln(walkers) dependent steps) adds ~5 ms; only a smaller G shortens that tail.
+#define IDX_RANGE_LOG2 20
+#define IDX_MAX_BUCKETS 4096
+#define IDX_THREADS 512
+#define IDX_PER_THREAD 32
+#define IDX_CHUNK (IDX_THREADS * IDX_PER_THREAD)      // entries of one log chunk (= one tile of bucket_indices_kernel)
+#define IDX_FILL_STRIDE 32            // u32 words between two bucket counters (128 bytes)
+#define MARK_LOG 0
+#define MARK_SENTINEL 1
+#define MARK_BYTEMAP 2
+template <int MARK>
+__global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, u8 *__restrict__ marks, u32 *__restrict__ idxlog, u64 s, u64 node_cap, int g, u32 slot,
                                                           const u64 *__restrict__ Cg, u8 *__restrict__ seg,
                                                           u32 *__restrict__ nxt, u32 *__restrict__ seglen,
                                                           u32 *__restrict__ segmin, u32 *__restrict__ segminoff,
                                                           unsigned long long *__restrict__ ticket,
                                                           unsigned long long *__restrict__ vcount,
-                                                          unsigned long long *__restrict__ overflow)
+                                                          unsigned long long *__restrict__ overflow,
+                                                          unsigned long long *__restrict__ chunk_ctr, u32 *__restrict__ chunk_fill, u64 log_chunks)
 {
     __shared__ u64 Ctab[257];
     for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
@@ -143,6 +166,12 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
     u32 sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;     // 16 recorded symbols waiting for one 16-byte store
     u64 bnext = 0, bend = 0;            // the wave's current batch of splitter ids (wave-uniform)
     bool exhausted = false;
+#ifdef WALK_PROFILE
+    unsigned long long *prof = ticket + 8;
+    if (lane_id() == 0) atomicMin(&prof[0], (unsigned long long)wall_clock64());
+    bool stamped = false;
+#endif
+    u64 lcur = 0, lbase = 0, lend = 0;  // MARK_LOG: the wave's open log chunk [lbase, lend) and its fill cursor (wave-uniform)
     for (;;) {
         const u64 need = __ballot(!have && !done);
         if (need) {
@@ -154,6 +183,9 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                 bnext = basev;
                 bend = basev + WALK_BATCH < s ? basev + WALK_BATCH : s;
                 if (basev >= s) { exhausted = true; bnext = bend = 0; }
+#ifdef WALK_PROFILE
+                if (exhausted && !stamped) { stamped = true; if (lane_id() == leader) { atomicMin(&prof[1], (unsigned long long)wall_clock64()); atomicMax(&prof[3], (unsigned long long)wall_clock64()); } }
+#endif
             }
             if (!have && !done) {
                 const u64 id = bnext + (u64)__popcll(need & lanemask_lt());
@@ -164,9 +196,31 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
             bnext = taken < bend ? taken : bend;
         }
         if (__ballot(have || !done) == 0) break;     // every lane has seen the counter run dry
+        if (MARK == MARK_LOG) {
+            // the indices the wave visits in this step go to its log back to back: one contiguous store per wave
+            const u64 act = __ballot(have);
+            const u32 na = (u32)__popcll(act);
+            if (na) {
+                if (lcur + na > lend) {
+                    const int leader = __ffsll((unsigned long long)act) - 1;
+                    unsigned long long cid = 0;
+                    if (lane_id() == leader) {
+                        if (lend) chunk_fill[lbase / IDX_CHUNK] = (u32)(lcur - lbase);
+                        cid = atomicAdd(chunk_ctr, 1ull);
+                        if (cid >= log_chunks) { atomicAdd(overflow, 1ull); cid = log_chunks - 1; }   // cannot happen (host sizes the log); stay in bounds
+                    }
+                    cid = shfl_t((u64)cid, leader);
+                    lbase = lcur = cid * IDX_CHUNK;
+                    lend = lbase + IDX_CHUNK;
+                }
+                if (have) idxlog[lcur + (u64)__popcll(act & lanemask_lt())] = x;
+                lcur += na;
+            }
+        }
         if (have) {
             const u32 y = LF[x];
-            if (BYTEMARK) marks[x] = 1; else LF[x] = LF_VISITED;      // the entry is not needed again; byte map only when 0xffffffff is a valid value
+            if (MARK == MARK_BYTEMAP) marks[x] = 1;
+            else if (MARK == MARK_SENTINEL) LF[x] = LF_VISITED;       // the entry is not needed again
             {
                 const u32 sh = symbol_of(Ctab, y) << (8 * (len & 3u));
                 const u32 w = (len >> 2) & 3u;
@@ -180,7 +234,8 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
             x = y;
             const bool at_splitter = (x & gmask) == 0;
             if (at_splitter || len == slot) {
-                if (len & 15u) *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);   // slot is a multiple of 16
+                if (len & 15u)                                                                               // slot is a multiple of 16
+                    *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);
                 u64 next_node;
                 if (at_splitter) {
                     next_node = x >> g;
@@ -194,6 +249,10 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
             } else if (x < mn) { mn = x; mnoff = len; }
         }
     }
+    if (MARK == MARK_LOG && lend && lane_id() == 0) chunk_fill[lbase / IDX_CHUNK] = (u32)(lcur - lbase);
+#ifdef WALK_PROFILE
+    if (lane_id() == 0) { atomicMax(&prof[2], (unsigned long long)wall_clock64()); atomicMin(&prof[4], (unsigned long long)wall_clock64()); }
+#endif
 }
 
 // out[end_c - t] = B[LF^t(min_c)] (unbwts.c:73-82): node v's recorded symbols go to out[opos - i], wrapping to the
@@ -215,7 +274,7 @@ __global__ __launch_bounds__(256) void place_segments_kernel(const u8 *__restric
 // ------------------------------------------------------------------------------------
 // elements no walk reached (cycles without a splitter): one sweep, wave-aggregated append
 // ------------------------------------------------------------------------------------
-template <bool BYTEMARK>
+template <int MARK>
 __global__ __launch_bounds__(256) void collect_unvisited_kernel(const u32 *__restrict__ LF, const u8 *__restrict__ marks, u64 n,
                                                                 u32 *__restrict__ uidx, u32 *__restrict__ ulf, u64 cap,
                                                                 unsigned long long *__restrict__ count)
@@ -225,7 +284,7 @@ __global__ __launch_bounds__(256) void collect_unvisited_kernel(const u32 *__res
         bool un = false;
         u32 v = 0;
         if (i < n) {
-            if (BYTEMARK) { un = marks[i] == 0; if (un) v = LF[i]; }
+            if (MARK == MARK_BYTEMAP) { un = marks[i] == 0; if (un) v = LF[i]; }
             else { v = LF[i]; un = v != LF_VISITED; }
         }
         const u64 m = __ballot(un);
@@ -237,6 +296,102 @@ __global__ __launch_bounds__(256) void collect_unvisited_kernel(const u32 *__res
             if (un) {
                 const u64 at = b + (u64)__popcll(m & lanemask_lt());
                 if (at < cap) { uidx[at] = (u32)i; ulf[at] = v; }
+            }
+        }
+    }
+}
+
+// ---- index-log mode: which indices did no walk log? ------------------------------------------------------------------
+// Step 1: the logged indices are appended to buckets of 2^IDX_RANGE_LOG2 consecutive index values.  A workgroup takes
+// one log chunk (its first chunk_fill[] entries): counts per bucket in LDS, reserves room in every bucket the chunk
+// touches (one global atomic each; the counters sit on separate cache lines), orders the chunk by bucket in LDS and
+// copies it out, so a bucket's share leaves as one contiguous run instead of one request per entry.
+// Step 2: one workgroup per bucket sets a bit per logged index in an LDS bitmap and reports the zero bits.
+static inline size_t bucket_indices_lds_bytes(u32 nbuckets) { return (size_t)IDX_CHUNK * 4 + 2 * (size_t)nbuckets * 4; }
+__global__ __launch_bounds__(IDX_THREADS) void bucket_indices_kernel(const u32 *__restrict__ idxlog, const u32 *__restrict__ chunk_fill,
+                                                                     u32 nbuckets, u32 *__restrict__ bucket_fill,
+                                                                     u32 *__restrict__ bucket_data)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 idx_lds[];
+    u32 *sorted = idx_lds;                    // IDX_CHUNK entries ordered by bucket
+    u32 *cnt = idx_lds + IDX_CHUNK;           // per bucket: count, then the fill cursor within `sorted`
+    u32 *delta = cnt + nbuckets;              // per bucket: (reserved offset in the bucket) - (start in `sorted`)
+    __shared__ u32 scan_sm[IDX_THREADS / 64];
+    const int tid = threadIdx.x;
+    const u32 clen = chunk_fill[blockIdx.x];
+    if (clen == 0) return;
+    const u32 *src = idxlog + (u64)blockIdx.x * IDX_CHUNK;
+    u32 x[IDX_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < IDX_PER_THREAD; q++) {
+        const u32 i = (u32)q * IDX_THREADS + tid;
+        x[q] = i < clen ? src[i] : 0u;
+    }
+    for (u32 b = tid; b < nbuckets; b += IDX_THREADS) cnt[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < IDX_PER_THREAD; q++)
+        if ((u32)q * IDX_THREADS + tid < clen) atomicAdd(&cnt[x[q] >> IDX_RANGE_LOG2], 1u);
+    __syncthreads();
+    // exclusive scan of the counts -> start of each bucket's run in `sorted`; room in the bucket from a global atomic
+    {
+        const u32 per = (nbuckets + IDX_THREADS - 1) / IDX_THREADS;      // buckets a thread scans (<= 8)
+        u32 c[8], run = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 b = (u32)tid * per + j;
+            c[j] = (u32)j < per && b < nbuckets ? cnt[b] : 0u;
+            run += c[j];
+        }
+        u32 tot;
+        u32 exc = block_scan_exclusive<u32, OpAdd, IDX_THREADS / 64>(run, OpAdd(), 0u, scan_sm, &tot);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 b = (u32)tid * per + j;
+            if ((u32)j < per && b < nbuckets) {
+                const u32 g = c[j] ? atomicAdd(&bucket_fill[(size_t)b * IDX_FILL_STRIDE], c[j]) : 0u;
+                cnt[b] = exc;
+                delta[b] = g - exc;
+                exc += c[j];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < IDX_PER_THREAD; q++)
+        if ((u32)q * IDX_THREADS + tid < clen) sorted[atomicAdd(&cnt[x[q] >> IDX_RANGE_LOG2], 1u)] = x[q];
+    __syncthreads();
+    for (u32 i = tid; i < clen; i += IDX_THREADS) {
+        const u32 v = sorted[i], b = v >> IDX_RANGE_LOG2;
+        bucket_data[((u64)b << IDX_RANGE_LOG2) + (u32)(delta[b] + i)] = v;
+    }
+}
+
+__global__ __launch_bounds__(1024) void unvisited_from_buckets_kernel(const u32 *__restrict__ bucket_fill, const u32 *__restrict__ bucket_data,
+                                                                      const u32 *__restrict__ LF, u64 n, u32 *__restrict__ uidx,
+                                                                      u32 *__restrict__ ulf, u64 cap, unsigned long long *__restrict__ count)
+{
+    extern __shared__ __attribute__((aligned(16))) u32 bm[];      // 2^IDX_RANGE_LOG2 bits = 128 KB (dynamic: above the static limit)
+    const u32 b = blockIdx.x;
+    for (u32 w = threadIdx.x; w < (1u << IDX_RANGE_LOG2) / 32; w += 1024) bm[w] = 0;
+    __syncthreads();
+    const u32 fill = bucket_fill[(size_t)b * IDX_FILL_STRIDE];
+    const u32 *src = bucket_data + ((u64)b << IDX_RANGE_LOG2);
+    for (u32 i = threadIdx.x; i < fill; i += 1024) {
+        const u32 o = src[i] & ((1u << IDX_RANGE_LOG2) - 1u);
+        atomicOr(&bm[o >> 5], 1u << (o & 31u));
+    }
+    __syncthreads();
+    const u64 lo = (u64)b << IDX_RANGE_LOG2;
+    for (u32 w = threadIdx.x; w < (1u << IDX_RANGE_LOG2) / 32; w += 1024) {
+        u32 zeros = ~bm[w];
+        while (zeros) {
+            const u32 bit = (u32)__ffs((int)zeros) - 1u;
+            zeros &= zeros - 1u;
+            const u64 x = lo + (u64)w * 32 + bit;
+            if (x < n) {
+                const unsigned long long at = atomicAdd(count, 1ull);      // rare: a few thousand on natural inputs
+                if (at < cap) { uidx[at] = (u32)x; ulf[at] = LF[x]; }
             }
         }
     }
@@ -368,7 +523,7 @@ static int grid1(u64 m) { return (int)((m + 255) / 256); }
 
 // One attempt with splitter spacing 2^g.  *retry is set when more elements sit in splitter-free cycles than
 // the sweep collects; the caller then repeats with g = 0 (every element a splitter: plain pointer jumping).
-static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int g, bool bytemark, bool *retry, bool *ambiguous)
+static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int g, int mark, bool *retry, bool *ambiguous)
 {
     *retry = false;
     *ambiguous = false;
@@ -380,8 +535,14 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     const u32 slot = (u32)(4 * G < 16 ? 16 : 4 * G);
     const u64 node_cap = g == 0 ? s : s + s / 8 + 1024;
     const size_t s4 = align_up(node_cap * 4, 256);
+    u64 walker_cap = 524288;
+    if (const char *e = getenv("BWTS_WALKERS")) { const long v = atol(e); if (v >= 256 && v <= (1 << 22)) walker_cap = (u64)v; }
+    const u64 walkers = s < walker_cap ? s : walker_cap;
+    const unsigned wblocks = (unsigned)((walkers + 255) / 256);
+    const u64 log_chunks = n / (IDX_CHUNK - 64) + (u64)wblocks * 4 + 2;     // a closed chunk wastes < 64 entries; every wave may leave one open
     BWTS_TRY(arena_reserve(ctx, align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 24 * s4 +
                                     align_up(node_cap * sizeof(CycleRec), 256) + align_up(node_cap * slot, 256) + align_up(n, 256) +
+                                    (mark == MARK_LOG ? align_up(log_chunks * IDX_CHUNK * 4, 256) + align_up(log_chunks * 4, 256) + align_up(n * 4 + (4ull << IDX_RANGE_LOG2), 256) + (1 << 20) : 0) +
                                     (1 << 16)));
     u32 *LF = arena_array<u32>(ctx, n);
     u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
@@ -390,8 +551,16 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     for (int i = 0; i < 20; i++) node[i] = arena_array<u32>(ctx, node_cap);
     CycleRec *d_recs = (CycleRec *)arena_alloc(ctx, node_cap * sizeof(CycleRec));
     u8 *seg = arena_array<u8>(ctx, node_cap * slot);
+    const bool bytemark = mark == MARK_BYTEMAP;
     u8 *marks = bytemark ? arena_array<u8>(ctx, n) : nullptr;
-    if (!LF || !tile_hist || !scan_temp || !node[19] || !d_recs || !seg || (bytemark && !marks)) return BWTS_E_NOMEM;
+    const u32 nbuckets = (u32)((n + (1ull << IDX_RANGE_LOG2) - 1) >> IDX_RANGE_LOG2);
+    u32 *idxlog = mark == MARK_LOG ? arena_array<u32>(ctx, log_chunks * IDX_CHUNK) : nullptr;
+    u32 *chunk_fill = mark == MARK_LOG ? arena_array<u32>(ctx, log_chunks) : nullptr;
+    u32 *bucket_data = mark == MARK_LOG ? arena_array<u32>(ctx, (u64)nbuckets << IDX_RANGE_LOG2) : nullptr;
+    u32 *bucket_fill = mark == MARK_LOG ? arena_array<u32>(ctx, (u64)IDX_MAX_BUCKETS * IDX_FILL_STRIDE) : nullptr;
+    if (!LF || !tile_hist || !scan_temp || !node[19] || !d_recs || !seg || (bytemark && !marks) ||
+        (mark == MARK_LOG && (!idxlog || !chunk_fill || !bucket_data || !bucket_fill)))
+        return BWTS_E_NOMEM;
     if (bytemark) HIPC(hipMemsetAsync(marks, 0, n, ctx->stream));
     u32 *nxt = node[0], *seglen = node[1], *segmin = node[2], *segoff = node[3];
     u32 *d_opos = node[4], *d_wrap = node[5], *d_clen = node[6];
@@ -423,21 +592,34 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
 
     // the walk: marks, segment symbols, reduced list
     unsigned long long *ticket = (unsigned long long *)(ctx->d_small + SMI_COUNTERS);
-    HIPC(hipMemsetAsync(ticket, 0, 8 * sizeof(u64), ctx->stream));
-    const u64 walkers = s < 524288 ? s : 524288;
-    const unsigned wblocks = (unsigned)((walkers + 255) / 256);
+    HIPC(hipMemsetAsync(ticket, 0, 16 * sizeof(u64), ctx->stream));
+#ifdef WALK_PROFILE
+    HIPC(hipMemsetAsync(ticket + 8, 0xff, 2 * sizeof(u64), ctx->stream));
+    HIPC(hipMemsetAsync(ticket + 12, 0xff, 1 * sizeof(u64), ctx->stream));
+#endif
+    if (mark == MARK_LOG) HIPC(hipMemsetAsync(chunk_fill, 0, log_chunks * sizeof(u32), ctx->stream));
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 6 * n);
-        if (bytemark)
-            walk_record_kernel<true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, s, node_cap, g, slot, dC, seg, nxt, seglen, segmin,
-                                                                                  segoff, ticket, ticket + 3, ticket + 4);
+        if (mark == MARK_BYTEMAP)
+            walk_record_kernel<MARK_BYTEMAP><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, nxt, seglen,
+                                                                                          segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks);
+        else if (mark == MARK_SENTINEL)
+            walk_record_kernel<MARK_SENTINEL><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, nxt, seglen,
+                                                                                           segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks);
         else
-            walk_record_kernel<false><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, s, node_cap, g, slot, dC, seg, nxt, seglen, segmin,
-                                                                                   segoff, ticket, ticket + 3, ticket + 4);
+            walk_record_kernel<MARK_LOG><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, nxt, seglen,
+                                                                                      segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks);
         HIPC(hipGetLastError());
     }
     // virtual nodes join the reduced list: its size is only known now
-    BWTS_TRY(read_small(ctx, SMI_COUNTERS, 8));
+    BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
+#ifdef WALK_PROFILE
+    {
+        const u64 *pf = ctx->h_small + SMI_COUNTERS + 8;
+        fprintf(stderr, "walk profile (ms from first wave start): first-exhausted %.2f  last-exhausted %.2f  first-wave-end %.2f  last-wave-end %.2f\n",
+                (pf[1] - pf[0]) / 1e5, (pf[3] - pf[0]) / 1e5, (pf[4] - pf[0]) / 1e5, (pf[2] - pf[0]) / 1e5);
+    }
+#endif
     if (ctx->h_small[SMI_COUNTERS + 4]) { *retry = true; return BWTS_OK; }   // node pool exhausted (adversarial LF): plain pointer jumping
     const u64 s_all = s + ctx->h_small[SMI_COUNTERS + 3];
 
@@ -448,10 +630,24 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     {
         SpanGuard sg(ctx, BWTS_K_OTHER, n, 4 * n);
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
-        if (bytemark)
-            collect_unvisited_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, UNV_CAP, ticket + 1);
+        if (mark == MARK_LOG) {
+            HIPC(hipMemsetAsync(bucket_fill, 0, (size_t)nbuckets * IDX_FILL_STRIDE * sizeof(u32), ctx->stream));
+            static bool attr_set = false;
+            const int bm_bytes = (int)((1u << IDX_RANGE_LOG2) / 8);
+            if (!attr_set) {
+                HIPC(hipFuncSetAttribute((const void *)unvisited_from_buckets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bm_bytes));
+                HIPC(hipFuncSetAttribute((const void *)bucket_indices_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)bucket_indices_lds_bytes(IDX_MAX_BUCKETS)));
+                attr_set = true;
+            }
+            bucket_indices_kernel<<<dim3((unsigned)log_chunks), dim3(IDX_THREADS), bucket_indices_lds_bytes(nbuckets), ctx->stream>>>(
+                idxlog, chunk_fill, nbuckets, bucket_fill, bucket_data);
+            unvisited_from_buckets_kernel<<<dim3(nbuckets), dim3(1024), bm_bytes, ctx->stream>>>(bucket_fill, bucket_data, LF, n, uidx, ulf, UNV_CAP,
+                                                                                                ticket + 1);
+        } else if (mark == MARK_BYTEMAP)
+            collect_unvisited_kernel<MARK_BYTEMAP><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, UNV_CAP, ticket + 1);
         else
-            collect_unvisited_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, UNV_CAP, ticket + 1);
+            collect_unvisited_kernel<MARK_SENTINEL><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, UNV_CAP, ticket + 1);
         HIPC(hipGetLastError());
     }
 
@@ -518,7 +714,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
                 const u32 nx = h_ulf[at];
                 const auto it = std::lower_bound(h_uidx.begin(), h_uidx.end(), nx);
                 if (it == h_uidx.end() || *it != nx) {
-                    if (!bytemark && n == 0x100000000ull) { *ambiguous = true; return BWTS_OK; }   // see the length check below
+                    if (mark == MARK_SENTINEL && n == 0x100000000ull) { *ambiguous = true; return BWTS_OK; }   // see the length check below
                     return BWTS_E_INTERNAL;
                 }
                 at = (u64)(it - h_uidx.begin());
@@ -542,7 +738,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         }
         if (used != n) {
             // n = 2^32 only: the one entry whose value equals LF_VISITED sat in a splitter-free cycle and was taken for visited
-            if (!bytemark && n == 0x100000000ull) { *ambiguous = true; return BWTS_OK; }
+            if (mark == MARK_SENTINEL && n == 0x100000000ull) { *ambiguous = true; return BWTS_OK; }
             return BWTS_E_INTERNAL;
         }
     }
@@ -591,15 +787,21 @@ int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
     if (n > 0x100000000ull) return BWTS_E_RANGE;
     bool retry = false, ambiguous = false;
-    bool bytemark = getenv("BWTS_BYTEMARK") != nullptr;      // test hook; otherwise only after an ambiguous first attempt
-    BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), bytemark, &retry, &ambiguous));
-    if (ambiguous) {
-        bytemark = true;
-        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), bytemark, &retry, &ambiguous));
+    // how visited entries are recorded: index log (default), or the two mark forms (BWTS_INV_MARK=sentinel|bytemap,
+    // BWTS_BYTEMARK=1: tests, and the fallback chain below)
+    int mark = MARK_LOG;
+    const char *me = getenv("BWTS_INV_MARK");
+    if (me && !strcmp(me, "sentinel")) mark = MARK_SENTINEL;
+    if ((me && !strcmp(me, "bytemap")) || getenv("BWTS_BYTEMARK")) mark = MARK_BYTEMAP;
+    BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous));
+    if (ambiguous) {            // sentinel marks only, n = 2^32: 0xffffffff was a real entry of a splitter-free cycle
+        mark = MARK_BYTEMAP;
+        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous));
     }
     if (retry) {
-        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, bytemark, &retry, &ambiguous));
-        if (ambiguous) BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, true, &retry, &ambiguous));
+        if (mark == MARK_LOG) mark = MARK_SENTINEL;        // adversarial LF: keep the retry on the simplest marks
+        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, mark, &retry, &ambiguous));
+        if (ambiguous) BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, MARK_BYTEMAP, &retry, &ambiguous));
         if (retry || ambiguous) return BWTS_E_INTERNAL;
     }
     return BWTS_OK;

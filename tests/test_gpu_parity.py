@@ -280,6 +280,7 @@ def test_cli_end_to_end(tmp_path):
     {"BWTS_VARLEN": "0", "BWTS_KEY_SYMBOLS": "2"},    # fixed-width keys of two symbols: nearly everything tied, dense ranks
     {"BWTS_LYNDON": "general"},                       # factors from a full suffix sort + prefix minima of ISA
     {"BWTS_EMIT": "gather"},                          # classic bwts[r] = P[sa[r]] gather instead of the carried byte
+    {"BWTS_INV_MARK": "sentinel"},                    # inverse marks visited entries in place instead of logging them
     {"BWTS_BYTEMARK": "1"},                           # inverse marks in a byte map (the n = 2^32 fallback)
     {"BWTS_SPLIT_LOG2": "0"},                         # inverse: every element a splitter (plain pointer jumping)
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))

@@ -1,7 +1,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
-pkg = ge.load_package(); ctx = pkg.Context(0)
+pkg = ge.load_package()
+if os.environ.get('BWTS_LIB'): pkg.LIB_PATH = os.environ['BWTS_LIB']
+ctx = pkg.Context(0)
 n = 1 << 30
 a, b = ctx.alloc(n), ctx.alloc(n)
 ctx.generate("zipf", 1, n, a)
