@@ -190,10 +190,17 @@ def main(argv=None):
         # dominant kernel: the n-sized LSD passes of round 0 (one template variant, timed under its own class)
         sc = agg.get("radix_scatter_main") or agg.get("radix_scatter", {"ms": 0.0, "launches": 0, "alg_bytes": 0})
         achieved = sc["alg_bytes"] / 1e9 / (sc["ms"] / 1e3) if sc["ms"] > 0 else 0.0
+        # which variant that was follows from its algorithmic bytes per element (20/18: packed streams, 26: wide pairs)
+        per_elem = sc["alg_bytes"] // max(sc["launches"], 1) // max(n, 1) if sc["launches"] else 0
+        kernel_label = {
+            20: "radix_scatter_packed_kernel<false,false,true> (8-bit LSD pass over packed streams: key-low 4 B + value 4 B + key-high|carried byte 2 B)",
+            18: "radix_scatter_packed_kernel<false,false,false> (8-bit LSD pass over packed streams: key 4 B + value 4 B + carried byte 1 B)",
+        }.get(per_elem, "radix_scatter2_kernel<512,16,4,true,false> (8-bit LSD pass, key 8 B + value 4 B + carried byte)")
         traffic = None
         try:    # PMC bytes per launch, collected with rocprofv3 --pmc on this workload (profiles/), only valid for 2^30
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_radix_scatter.json")))
-            if args.log2n == 30 and args.workload == "zipf":
+            if args.log2n == 30 and args.workload == "zipf" and pm.get("kernel", "").split("<")[0] == kernel_label.split("<")[0] \
+                    and pm.get("alg_bytes_per_element") == per_elem:
                 traffic = pm["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -206,7 +213,7 @@ def main(argv=None):
                        "bytes_per_gpu": n, "parallelism": "replicas x%d (one input per GPU, RCCL barrier only)" % n_gpus},
             "inverse_MBps": round(inv_value, 2), "inverse_ms_per_step": round(1e3 * inv_s / max(args.inverse_steps, 1), 3),
             "roundtrip_exact": bad == 0.0,
-            "roofline": {"bound": "hbm", "kernel": "radix_scatter2_kernel<512,16,4,true,false> (8-bit LSD pass, key 8 B + value 4 B + carried byte)",
+            "roofline": {"bound": "hbm", "kernel": kernel_label,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "alg_bytes_per_launch": sc["alg_bytes"] // max(sc["launches"], 1),

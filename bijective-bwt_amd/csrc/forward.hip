@@ -775,6 +775,88 @@ struct GroupOut {
     }
 };
 
+// ---- round 0 at word granularity ---------------------------------------------------------------------------------------
+// The n-sized round needs the sorted keys only to know where groups start (f0) and which elements sit in a group of more
+// than one (keep).  group_flags_kernel reads the keys once and leaves both as bitmaps (one u64 per 64 slots, straight
+// from __ballot); the scan then runs over n/64 words instead of n elements, and tied_from_flags_kernel turns the set
+// bits into the tied list.  Same outputs as GroupIn/GroupOut with rb < 0, a third of the time.
+#define GF_WORDS 8      // words (of 64 slots) a wave handles per step: eight key loads in flight per lane
+__global__ __launch_bounds__(256) void group_flags_kernel(const u64 *__restrict__ K, u64 n, u64 *__restrict__ headw, u64 *__restrict__ keepw)
+{
+    const int lane = lane_id();
+    const u64 words = (n + 63) / 64;
+    const u64 wave = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6, waves = ((u64)gridDim.x * 256) >> 6;
+    for (u64 w0 = wave * GF_WORDS; w0 < words; w0 += waves * GF_WORDS) {
+        u64 k[GF_WORDS];
+#pragma unroll
+        for (int q = 0; q < GF_WORDS; q++) {
+            const u64 i = (w0 + q) * 64 + lane;
+            k[q] = i < n ? K[i] : 0;
+        }
+        const u64 first = w0 * 64, last = (w0 + GF_WORDS) * 64 - 1;      // the chunk's outer neighbours
+        u64 edge = 0;
+        if (lane == 0 && first > 0) edge = K[first - 1];
+        if (lane == 63 && last + 1 < n) edge = K[last + 1];
+        u64 mine_h = 0, mine_k = 0;
+#pragma unroll
+        for (int q = 0; q < GF_WORDS; q++) {
+            const u64 i = (w0 + q) * 64 + lane;
+            u64 kp = shfl_up_t(k[q], 1), kn = shfl_down_t(k[q], 1);
+            const u64 prev63 = q > 0 ? shfl_t(k[q > 0 ? q - 1 : 0], 63) : edge;              // lane 0 reads it
+            const u64 next0 = q + 1 < GF_WORDS ? shfl_t(k[q + 1 < GF_WORDS ? q + 1 : q], 0) : edge;   // lane 63 reads it
+            if (lane == 0) kp = prev63;
+            if (lane == 63) kn = next0;
+            const bool valid = i < n;
+            const bool f0 = valid && (i == 0 || k[q] != kp);
+            const bool f1 = valid && (i + 1 == n || kn != k[q]);
+            const u64 hm = __ballot(f0), km = __ballot(valid && !(f0 && f1));
+            if (lane == q) { mine_h = hm; mine_k = km; }
+        }
+        if (lane < GF_WORDS && w0 + lane < words) { headw[w0 + lane] = mine_h; keepw[w0 + lane] = mine_k; }
+    }
+}
+
+// scan element of a word: (slot of its last group start, 0 if none) : (number of tied slots)
+struct WordIn {
+    const u64 *headw, *keepw;
+    __device__ __forceinline__ u64 operator()(u64 w) const
+    {
+        const u64 hm = headw[w], km = keepw[w];
+        const u64 pos = hm ? w * 64 + (u64)(63 - __clzll((long long)hm)) : 0ull;
+        return (pos << 32) | (u64)__popcll(km);
+    }
+};
+
+__global__ __launch_bounds__(256) void tied_from_flags_kernel(const u64 *__restrict__ headw, const u64 *__restrict__ keepw,
+                                                              const u64 *__restrict__ pre, u64 n, const u32 *__restrict__ V,
+                                                              u32 *__restrict__ n_idx, u32 *__restrict__ n_slot, u32 *__restrict__ n_head,
+                                                              u64 *__restrict__ cnt_active)
+{
+    const int lane = lane_id();
+    const u64 words = (n + 63) / 64;
+    const u64 wave = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6, waves = ((u64)gridDim.x * 256) >> 6;
+    for (u64 wb = wave * 64; wb < words; wb += waves * 64) {
+        // lane l holds word wb + l; words with tied slots are then expanded one at a time by the whole wave
+        const u64 w = wb + lane;
+        u64 hm = 0, km = 0, pr = 0;
+        if (w < words) { hm = headw[w]; km = keepw[w]; pr = pre[w]; }
+        if (w + 1 == words) *cnt_active = (u64)(u32)pr + (u64)__popcll(km);
+        u64 todo = __ballot(km != 0);
+        while (todo) {
+            const int q = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const u64 h = shfl_t(hm, q), kk = shfl_t(km, q), pq = shfl_t(pr, q);
+            if ((kk >> lane) & 1ull) {
+                const u64 i = (wb + q) * 64 + lane;
+                const u64 below = lane == 63 ? h : h & ((2ull << lane) - 1ull);        // group starts at or before this slot
+                const u32 head = below ? (u32)((wb + q) * 64 + (u64)(63 - __clzll((long long)below))) : (u32)(pq >> 32);
+                const u32 dst = (u32)pq + (u32)__popcll(kk & lanemask_lt());
+                n_idx[dst] = V[i]; n_slot[dst] = (u32)i; n_head[dst] = head;
+            }
+        }
+    }
+}
+
 // rank[sa[i]] = i for every slot, then rank[idx] = head for the still-tied elements
 __global__ __launch_bounds__(256) void rank_from_sa_kernel(const u32 *__restrict__ SA, u64 n, u32 *__restrict__ rank)
 {
@@ -868,11 +950,27 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     cur.head = sp.vals[res ^ 1];
 
     HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
-    {
+    static const bool scan_by_keys = [] { const char *e = getenv("BWTS_GROUPSCAN"); return e && !strcmp(e, "keys"); }();
+    if (scan_by_keys) {             // the element-wise scan the later rounds use (kept selectable for tests)
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
         GroupIn in{K0, nullptr, n, -1};
         GroupOut out{nullptr, SA, n, -1, nullptr, nullptr, nullptr, 0, SA, cur.idx, cur.slot, cur.head, cnt + 0, cnt + 1};
         BWTS_TRY((device_scan<true, u64>(ctx, n, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
+    } else {
+        SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
+        // sp.rank (4n bytes) is not needed before the rounds that follow: flags and word prefixes live there
+        const u64 words = (n + 63) / 64;
+        u64 *headw = (u64 *)sp.rank, *keepw = headw + words, *pre = keepw + words;      // 3 * n/8 bytes
+        u64 waves = (words + GF_WORDS - 1) / GF_WORDS;
+        unsigned blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
+        group_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(K0, n, headw, keepw);
+        WordIn in{headw, keepw};
+        ScanStoreArr<u64> out{pre};
+        BWTS_TRY((device_scan<false, u64>(ctx, words, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
+        waves = (words + 63) / 64;
+        blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
+        tied_from_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(headw, keepw, pre, n, SA, cur.idx, cur.slot, cur.head, cnt + 0);
+        HIPC(hipGetLastError());
     }
     BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
     u64 a = ctx->h_small[CNT_ACTIVE];

@@ -312,6 +312,327 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------
+// packed streams (round 0 of the forward transform)
+// ------------------------------------------------------------------------------------
+// A round-0 key has at most 40 significant bits, yet a pass of the kernel above moves 8 + 4 + 1 bytes per element.
+// Between the first and the last pass the element travels instead as
+//     lo  u32   key bits 0..31
+//     val u32   the position
+//     c   u16   key bits 32..39 | carried byte << 8        (HI16)   -- or u8: the carried byte alone (keys <= 32 bits)
+// = 10 (9) bytes, and a histogram sweep reads only the stream that holds its digit (4 or 2 bytes, not 8).
+// The first pass reads the wide keys keybuild wrote (value = index, IDENT) and the last pass writes wide keys again,
+// so everything downstream still sees sorted u64 keys.  Ranking, LDS staging and XCD mapping are those of
+// radix_scatter2_kernel; the LDS tile carries the digit's stream on its first trip and the other two on its second.
+template <typename T>
+__global__ __launch_bounds__(512) void radix_hist_packed_kernel(const T *__restrict__ src, u64 m, int shift, u32 *__restrict__ tile_hist)
+{
+    constexpr int RX_THREADS = 512, RX_ITEMS = 16, RX_WAVES = 8, RX_TILE = 8192;
+    __shared__ u32 bins[RX_WAVES][256];
+    const int tid = threadIdx.x, w = tid >> 6;
+    for (int i = tid; i < RX_WAVES * 256; i += RX_THREADS) ((u32 *)bins)[i] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * RX_TILE;
+    T k[RX_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const u64 i = base + (u64)j * RX_THREADS + tid;
+        k[j] = i < m ? src[i] : (T)0;
+    }
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const u64 i = base + (u64)j * RX_THREADS + tid;
+        if (i < m) atomicAdd(&bins[w][(u32)(k[j] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 256) {
+        u32 s = 0;
+#pragma unroll
+        for (int ww = 0; ww < RX_WAVES; ww++) s += bins[ww][tid];
+        tile_hist[(u64)blockIdx.x * 256 + tid] = s;
+    }
+}
+
+struct PackedIO {
+    const u64 *kin_wide; const u8 *sym_in;                 // IN_WIDE
+    const u32 *lo_in; const u32 *val_in; const void *c_in; // !IN_WIDE (c: u16 if HI16 else u8)
+    u64 *kout_wide; u8 *sym_out;                           // OUT_WIDE
+    u32 *lo_out; void *c_out;                              // !OUT_WIDE
+    u32 *val_out;
+};
+
+template <bool IN_WIDE, bool OUT_WIDE, bool HI16>
+__global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO io, const u32 *__restrict__ tile_off, u64 m, int shift)
+{
+    constexpr int RX_THREADS = 512, RX_ITEMS = 16, RX_WAVES = 8, RX_TILE = 8192;
+    extern __shared__ __attribute__((aligned(16))) char rx_smem[];
+    u64 *stage = (u64 *)rx_smem;                                   // RX_TILE x u32 (first trip), RX_TILE x uint2 (second)
+    u32 *dbase = (u32 *)(stage + RX_TILE);                         // 256
+    u32 *gbase = dbase + 256;                                      // 256
+    u32 *scan_sm = gbase + 256;                                    // RX_WAVES (padded to 16)
+    u16 (*whist)[256] = (u16 (*)[256])(scan_sm + 16);              // RX_WAVES x 256
+    u8 *sdig = (u8 *)(whist + RX_WAVES);                           // RX_TILE: digit of the element in slot s
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u64 tile = rx_tile_of_block((m + RX_TILE - 1) / RX_TILE);
+    const u64 tile_base = tile * RX_TILE;
+    if (tile_base >= m) return;                                   // padding block of the XCD-aligned grid
+    const u64 wave_base = tile_base + (u64)w * (64 * RX_ITEMS);
+    const u64 remain = m - tile_base;
+    const u32 tile_count = remain < RX_TILE ? (u32)remain : (u32)RX_TILE;
+
+    for (int i = tid; i < RX_WAVES * 128; i += RX_THREADS) ((u32 *)whist)[i] = 0;
+
+    // element j of this lane is i0 + 64 j; which of the sixteen exist is decided once (bit j of vmask), so that no
+    // 64-bit index has to stay alive for the bounds checks further down
+    const u64 i0 = wave_base + (u64)lane;
+    u32 vmask = 0;
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) vmask |= (i0 + (u64)j * 64 < m ? 1u : 0u) << j;
+#define PK_VALID(j) ((vmask >> (j)) & 1u)
+
+    // Only the stream that holds this pass's digit is loaded before the ranking and makes the first LDS trip alone;
+    // the other two are loaded while the first trip is written out and share the second trip.
+    // With 40-bit keys the fifth (= last) pass sorts by the byte that travels in c.
+    constexpr bool DIG_C = HI16 && OUT_WIDE;
+    u32 dsrc[RX_ITEMS];
+    u32 posp[RX_ITEMS / 2];
+    if (IN_WIDE) {
+        // the wide key as two words: the low one is this pass's digit stream and is loaded now; the high one (its low
+        // byte joins c) is fetched with the carried byte for the second trip -- its lines are still in L2, and holding
+        // it across the ranking costs spills
+        const u32 *klo = (const u32 *)io.kin_wide + 2 * i0;
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) dsrc[j] = PK_VALID(j) ? klo[j * 128] : ~0u;
+    } else {
+        const u16 *c16 = (const u16 *)io.c_in + i0;
+        const u32 *lop = io.lo_in + i0;
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) {
+            if (DIG_C) dsrc[j] = PK_VALID(j) ? (u32)c16[j * 64] : 0xffffu;
+            else dsrc[j] = PK_VALID(j) ? lop[j * 64] : ~0u;
+        }
+    }
+#define PK_DIGIT(j) (DIG_C ? (dsrc[j] & 255u) : ((dsrc[j] >> shift) & 255u))
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const bool valid = PK_VALID(j);
+        const u32 d = PK_DIGIT(j);
+        const u64 peers = match_digit8(d, valid);
+        const u32 before = (u32)__popcll(peers & lanemask_lt());
+        const u32 cnt = (u32)__popcll(peers);
+        const u32 prev = whist[w][d];
+        if (j & 1) posp[j >> 1] |= (prev + before) << 16; else posp[j >> 1] = prev + before;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid && before == 0) whist[w][d] = (u16)(prev + cnt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    __syncthreads();
+    {
+        u32 run = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int ww = 0; ww < RX_WAVES; ww++) {
+                const u32 cc = whist[ww][tid];
+                whist[ww][tid] = (u16)run;
+                run += cc;
+            }
+        }
+        u32 total;
+        const u32 exc = block_scan_exclusive<u32, OpAdd, RX_WAVES>(run, OpAdd(), 0u, scan_sm, &total);
+        if (tid < 256) {
+            dbase[tid] = exc;
+            gbase[tid] = tile_off[tile * 256 + tid] - exc;
+        }
+    }
+    __syncthreads();
+
+#define POS_GET(j) (((j) & 1) ? posp[(j) >> 1] >> 16 : posp[(j) >> 1] & 0xffffu)
+#define POS_SET(j, v) do { if ((j) & 1) posp[(j) >> 1] = (posp[(j) >> 1] & 0xffffu) | ((v) << 16); \
+                           else posp[(j) >> 1] = (posp[(j) >> 1] & 0xffff0000u) | (v); } while (0)
+    constexpr int HB = 8;
+    u32 *stage32 = (u32 *)stage;
+    // first trip: the digit's stream into its slot, the slot's digit into the byte table
+#pragma unroll
+    for (int j0 = 0; j0 < RX_ITEMS; j0 += HB) {
+        u32 add[HB];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 d = PK_DIGIT(j0 + jj);
+            add[jj] = dbase[d] + whist[w][d];
+        }
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const int j = j0 + jj;
+            const bool valid = PK_VALID(j);
+            const u32 p = POS_GET(j) + add[jj];
+            POS_SET(j, p);
+            if (valid) { stage32[p] = dsrc[j]; sdig[p] = (u8)PK_DIGIT(j); }
+        }
+    }
+    // the other two streams: (lo, val) on the pass that sorts by c, else (val, c); their loads overlap the write-out below
+    u32 sa[RX_ITEMS], sb[RX_ITEMS];
+    {
+        const u32 *khi = (const u32 *)io.kin_wide + 2 * i0 + 1;      // key bits 32..39 (first pass; value = index, formed when staged)
+        const u32 *lop = io.lo_in + i0, *valp = io.val_in + i0;
+        const u8 *sym8 = io.sym_in + i0, *c8 = (const u8 *)io.c_in + i0;
+        const u16 *c16 = (const u16 *)io.c_in + i0;
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) {
+            if (IN_WIDE) sa[j] = (HI16 && PK_VALID(j)) ? khi[j * 128] : 0u;
+            else if (DIG_C) sa[j] = PK_VALID(j) ? lop[j * 64] : 0u;
+            else sa[j] = PK_VALID(j) ? valp[j * 64] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) {
+            if (IN_WIDE) sb[j] = PK_VALID(j) ? (u32)sym8[j * 64] : 0u;
+            else if (DIG_C) sb[j] = PK_VALID(j) ? valp[j * 64] : 0u;
+            else sb[j] = PK_VALID(j) ? (HI16 ? (u32)c16[j * 64] : (u32)c8[j * 64]) : 0u;
+        }
+    }
+    __syncthreads();
+    u32 hi_s[DIG_C ? RX_ITEMS : 1];                                // last 40-bit pass: the slot's key byte waits for its lo
+#pragma unroll
+    for (int j0 = 0; j0 < RX_ITEMS; j0 += HB) {
+        u32 x[HB], g[HB];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 s = (u32)(j0 + jj) * RX_THREADS + tid;
+            const u32 sc = s < tile_count ? s : 0u;
+            x[jj] = stage32[sc];
+            g[jj] = sdig[sc];
+        }
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) g[jj] = gbase[g[jj]];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 s = (u32)(j0 + jj) * RX_THREADS + tid;
+            if (DIG_C) hi_s[j0 + jj] = x[jj] & 255u;
+            if (s < tile_count) {
+                const u32 dst = g[jj] + s;
+                if (DIG_C) io.sym_out[dst] = (u8)(x[jj] >> 8);
+                else if (OUT_WIDE) io.kout_wide[dst] = (u64)x[jj];
+                else io.lo_out[dst] = x[jj];
+            }
+        }
+    }
+    __syncthreads();
+    // second trip: the pair.  (The index value is rebuilt from an opaque copy of the base: left to itself the compiler
+    // keeps the sixteen indices of the load addresses alive from the top of the kernel and spills them.)
+    u32 idx_base = (u32)wave_base + (u32)lane;
+    asm volatile("" : "+v"(idx_base));
+    if (IN_WIDE && HI16) {
+        // likewise the carried bytes stay raw in their sixteen registers until here: merged into `hi` on arrival they
+        // arrive one at a time, each load waiting for the one before (seen in the ISA: 9.3 ms instead of 5 for the pass)
+#pragma unroll
+        for (int j = 0; j < RX_ITEMS; j++) asm volatile("" : "+v"(sb[j]), "+v"(sa[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < RX_ITEMS; j++) {
+        const bool valid = PK_VALID(j);
+        const u32 second = (IN_WIDE && HI16) ? (sa[j] | (sb[j] << 8)) : sb[j];       // keys have <= 40 bits: high word < 256
+        const u32 firstw = IN_WIDE ? idx_base + (u32)j * 64u : sa[j];
+        if (valid) ((uint2 *)stage)[POS_GET(j)] = make_uint2(firstw, second);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j0 = 0; j0 < RX_ITEMS; j0 += HB) {
+        uint2 e[HB];
+        u32 g[HB];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 s = (u32)(j0 + jj) * RX_THREADS + tid;
+            const u32 sc = s < tile_count ? s : 0u;
+            e[jj] = ((const uint2 *)stage)[sc];
+            g[jj] = sdig[sc];
+        }
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) g[jj] = gbase[g[jj]];
+#pragma unroll
+        for (int jj = 0; jj < HB; jj++) {
+            const u32 s = (u32)(j0 + jj) * RX_THREADS + tid;
+            if (s < tile_count) {
+                const u32 dst = g[jj] + s;
+                if (DIG_C) {
+                    io.kout_wide[dst] = (u64)e[jj].x | ((u64)hi_s[j0 + jj] << 32);
+                    io.val_out[dst] = e[jj].y;
+                } else {
+                    io.val_out[dst] = e[jj].x;
+                    if (OUT_WIDE) io.sym_out[dst] = (u8)e[jj].y;
+                    else if (HI16) ((u16 *)io.c_out)[dst] = (u16)e[jj].y;
+                    else ((u8 *)io.c_out)[dst] = (u8)e[jj].y;
+                }
+            }
+        }
+    }
+#undef POS_GET
+#undef POS_SET
+#undef PK_DIGIT
+#undef PK_VALID
+}
+
+template <bool IN_WIDE, bool OUT_WIDE, bool HI16>
+static int launch_scatter_packed(bwts_ctx *ctx, u64 tiles, const PackedIO &io, const u32 *tile_off, u64 m, int shift)
+{
+    constexpr size_t lds = (size_t)8192 * 9 + 2048 + 64 + (size_t)8 * 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPC(hipFuncSetAttribute((const void *)radix_scatter_packed_kernel<IN_WIDE, OUT_WIDE, HI16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    radix_scatter_packed_kernel<IN_WIDE, OUT_WIDE, HI16><<<dim3((unsigned)rx_grid(tiles)), dim3(512), lds, ctx->stream>>>(io, tile_off, m, shift);
+    return BWTS_OK;
+}
+
+// round 0 with the byte stream and identity values, keys of 17..40 bits: wide -> packed ... packed -> wide
+template <bool HI16>
+static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int passes, int *result_buf)
+{
+    const u64 tiles = (m + 8191) / 8192;
+    u32 *tile_hist = plan.tile_hist;
+    const size_t lo_bytes = align_up((size_t)m * 4, 256);
+    const u64 pass_bytes = HI16 ? 20 : 18;
+    int cur = 0;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        const bool first = p == 0, last = p == passes - 1;
+        char *src = (char *)plan.keys[cur], *dst = (char *)plan.keys[cur ^ 1];
+        PackedIO io{};
+        io.kin_wide = plan.keys[cur]; io.sym_in = plan.sym_src;
+        io.lo_in = (const u32 *)src; io.c_in = src + lo_bytes; io.val_in = plan.vals[cur];
+        io.kout_wide = plan.keys[cur ^ 1]; io.sym_out = plan.sym_final;
+        io.lo_out = (u32 *)dst; io.c_out = dst + lo_bytes; io.val_out = plan.vals[cur ^ 1];
+        {
+            SpanGuard g(ctx, BWTS_K_RADIX_HIST, m, (first ? 8 : (HI16 && shift >= 32) ? 2 : 4) * m);
+            if (first) radix_hist_packed_kernel<u64><<<dim3((unsigned)tiles), dim3(512), 0, ctx->stream>>>(plan.keys[cur], m, shift, tile_hist);
+            else if (HI16 && shift >= 32) radix_hist_packed_kernel<u16><<<dim3((unsigned)tiles), dim3(512), 0, ctx->stream>>>((const u16 *)io.c_in, m, 0, tile_hist);
+            else radix_hist_packed_kernel<u32><<<dim3((unsigned)tiles), dim3(512), 0, ctx->stream>>>(io.lo_in, m, shift, tile_hist);
+        }
+        {
+            SpanGuard g(ctx, BWTS_K_RADIX_SCAN, tiles * 256, tiles * 256 * 12);
+            BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, plan.scan_temp));
+        }
+        if (first) {
+            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (9 + pass_bytes / 2) * m);
+            BWTS_TRY((launch_scatter_packed<true, false, HI16>(ctx, tiles, io, tile_hist, m, shift)));
+        } else if (last) {
+            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (pass_bytes / 2 + 13) * m);
+            BWTS_TRY((launch_scatter_packed<false, true, HI16>(ctx, tiles, io, tile_hist, m, shift)));
+        } else {
+            // timed a second time under its own class: the roofline kernel (one template variant, n-sized launches)
+            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, pass_bytes * m);
+            SpanGuard gm(ctx, BWTS_K_RADIX_SCATTER_MAIN, m, pass_bytes * m);
+            BWTS_TRY((launch_scatter_packed<false, false, HI16>(ctx, tiles, io, tile_hist, m, shift)));
+        }
+        HIPC(hipGetLastError());
+        cur ^= 1;
+    }
+    *result_buf = cur;
+    return BWTS_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------
 template <int TH, int IT>
@@ -380,6 +701,13 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
     const u64 tiles = radix_tiles(m);
     const int cfg = rx_config_index();
     u32 *tile_hist = plan.tile_hist;
+
+    // round 0 of the forward transform (byte stream + identity values) with keys of at most 40 bits: packed streams
+    static const bool packed_ok = [] { const char *e = getenv("BWTS_RX_PACK"); return !(e && atoi(e) == 0); }();
+    if (packed_ok && cfg == 0 && plan.sym_src && plan.vals_identity && passes >= 3 && passes <= 5 && m >= 65536) {
+        if (passes == 5) return radix_sort_packed<true>(ctx, plan, m, passes, result_buf);
+        return radix_sort_packed<false>(ctx, plan, m, passes, result_buf);
+    }
 
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;

@@ -280,6 +280,8 @@ def test_cli_end_to_end(tmp_path):
     {"BWTS_VARLEN": "0", "BWTS_KEY_SYMBOLS": "2"},    # fixed-width keys of two symbols: nearly everything tied, dense ranks
     {"BWTS_LYNDON": "general"},                       # factors from a full suffix sort + prefix minima of ISA
     {"BWTS_EMIT": "gather"},                          # classic bwts[r] = P[sa[r]] gather instead of the carried byte
+    {"BWTS_RX_PACK": "0"},                            # round-0 sort on wide (u64, u32, u8) streams instead of packed ones
+    {"BWTS_GROUPSCAN": "keys"},                       # round-0 group scan element-wise over the keys instead of flag words
     {"BWTS_INV_MARK": "sentinel"},                    # inverse marks visited entries in place instead of logging them
     {"BWTS_BYTEMARK": "1"},                           # inverse marks in a byte map (the n = 2^32 fallback)
     {"BWTS_SPLIT_LOG2": "0"},                         # inverse: every element a splitter (plain pointer jumping)
