@@ -101,6 +101,21 @@ __global__ __launch_bounds__(LF_THREADS) void lf_rank_kernel(const u8 *__restric
     }
 }
 
+// C[c] = first slot of symbol c = tile 0's offset in the scanned [tile][symbol] table; C[256] = n.  The table is 32-bit:
+// a boundary equal to 2^32 (n = 2^32, symbols above the largest one present) reads as a value below its predecessor.
+__global__ void ctab_from_tiles_kernel(const u32 *__restrict__ tile_off, u64 n, u64 *__restrict__ C)
+{
+    if (threadIdx.x != 0) return;
+    u64 prev = 0;
+    for (int c = 0; c < 256; c++) {
+        u64 v = tile_off[c];
+        if (v < prev) v += 0x100000000ull;
+        C[c] = v;
+        prev = v;
+    }
+    C[256] = n;
+}
+
 // ------------------------------------------------------------------------------------
 // splitter walk (the only pass that chases LF)
 // ------------------------------------------------------------------------------------
@@ -411,78 +426,79 @@ __global__ __launch_bounds__(256) void scatter_bytes_kernel(const u32 *__restric
 // id), length, smallest element, and the node's distance from that smallest element along LF.
 #define LR_NIL 0xffffffffu
 
-__global__ __launch_bounds__(256) void lr_init_kernel(u64 s, const u32 *__restrict__ nxt, const u32 *__restrict__ mn,
-                                                      u32 *__restrict__ lead, u32 *__restrict__ cmin, u32 *__restrict__ hop)
+// A round of pointer jumping reads the record of the node it hops to: the fields travel together (16 and 8 bytes), so
+// a round costs one random line fill per node instead of three (two).
+//   LrMin  x = smallest node id seen (-> leader), y = smallest element seen, z = hop target
+//   LrSum  x = segment lengths summed up to the cut, y = hop target (LR_NIL at the cut)
+typedef uint4 LrMin;
+typedef uint2 LrSum;
+
+__global__ __launch_bounds__(256) void lr_init_kernel(u64 s, const u32 *__restrict__ nxt, const u32 *__restrict__ mn, LrMin *__restrict__ rec)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (v < s) { lead[v] = (u32)v; cmin[v] = mn[v]; hop[v] = nxt[v]; }
+    if (v < s) rec[v] = make_uint4((u32)v, mn[v], nxt[v], 0u);
 }
 
 // after r rounds a node has folded in the 2^r nodes that follow it
-__global__ __launch_bounds__(256) void lr_jump_min_kernel(u64 s, const u32 *__restrict__ lead_in, const u32 *__restrict__ cmin_in,
-                                                          const u32 *__restrict__ hop_in, u32 *__restrict__ lead_out,
-                                                          u32 *__restrict__ cmin_out, u32 *__restrict__ hop_out)
+__global__ __launch_bounds__(256) void lr_jump_min_kernel(u64 s, const LrMin *__restrict__ in, LrMin *__restrict__ out)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
     if (v >= s) return;
-    const u32 h = hop_in[v];
-    const u32 l0 = lead_in[v], l1 = lead_in[h], c0 = cmin_in[v], c1 = cmin_in[h];
-    lead_out[v] = l0 < l1 ? l0 : l1;
-    cmin_out[v] = c0 < c1 ? c0 : c1;
-    hop_out[v] = hop_in[h];
+    const LrMin a = in[v];
+    const LrMin b = in[a.z];
+    out[v] = make_uint4(a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, b.z, 0u);
 }
 
 // cut every cycle in front of its leader, then suffix sums of the segment lengths
 __global__ __launch_bounds__(256) void lr_cut_kernel(u64 s, const u32 *__restrict__ nxt, const u32 *__restrict__ len,
-                                                     const u32 *__restrict__ lead, u32 *__restrict__ sum, u32 *__restrict__ hop)
+                                                     const LrMin *__restrict__ rec, LrSum *__restrict__ sh)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (v < s) { sum[v] = len[v]; hop[v] = nxt[v] == lead[v] ? LR_NIL : nxt[v]; }
+    if (v < s) { const u32 nx = nxt[v]; sh[v] = make_uint2(len[v], nx == rec[v].x ? LR_NIL : nx); }
 }
 
-__global__ __launch_bounds__(256) void lr_jump_sum_kernel(u64 s, const u32 *__restrict__ sum_in, const u32 *__restrict__ hop_in,
-                                                          u32 *__restrict__ sum_out, u32 *__restrict__ hop_out)
+__global__ __launch_bounds__(256) void lr_jump_sum_kernel(u64 s, const LrSum *__restrict__ in, LrSum *__restrict__ out)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
     if (v >= s) return;
-    const u32 h = hop_in[v];
-    if (h == LR_NIL) { sum_out[v] = sum_in[v]; hop_out[v] = LR_NIL; }
-    else { sum_out[v] = sum_in[v] + sum_in[h]; hop_out[v] = hop_in[h]; }
+    const LrSum a = in[v];
+    if (a.y == LR_NIL) out[v] = a;
+    else { const LrSum b = in[a.y]; out[v] = make_uint2(a.x + b.x, b.y); }
 }
 
 struct CycleRec { u32 leader; u32 minelem; u32 len; u32 pad; };
 
 // dist[v] = elements between the leader's splitter and v's splitter; the node whose segment holds the
 // cycle's smallest element publishes that element's distance; leaders append a cycle record
-__global__ __launch_bounds__(256) void lr_finish_kernel(u64 s, const u32 *__restrict__ lead, const u32 *__restrict__ cmin,
-                                                        const u32 *__restrict__ sum, const u32 *__restrict__ mn,
-                                                        const u32 *__restrict__ off, u32 *__restrict__ dist,
+__global__ __launch_bounds__(256) void lr_finish_kernel(u64 s, const LrMin *__restrict__ rec, const LrSum *__restrict__ sh,
+                                                        const u32 *__restrict__ mn, const u32 *__restrict__ off, u32 *__restrict__ dist,
                                                         u32 *__restrict__ min_dist /* by leader */, CycleRec *__restrict__ recs,
                                                         unsigned long long *__restrict__ nrec)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
     if (v >= s) return;
-    const u32 l = lead[v];
-    const u32 L = sum[l];
-    const u32 d = L - sum[v];
+    const LrMin r = rec[v];
+    const u32 l = r.x;
+    const u32 L = sh[l].x;
+    const u32 d = L - sh[v].x;
     dist[v] = d;
-    if (mn[v] == cmin[v]) min_dist[l] = d + off[v];
+    if (mn[v] == r.y) min_dist[l] = d + off[v];
     if (l == (u32)v) {
         const unsigned long long at = atomicAdd(nrec, 1ull);
-        CycleRec r; r.leader = l; r.minelem = cmin[v]; r.len = L; r.pad = 0;
-        recs[at] = r;
+        CycleRec c; c.leader = l; c.minelem = r.y; c.len = L; c.pad = 0;
+        recs[at] = c;
     }
 }
 
-__global__ __launch_bounds__(256) void lr_place_kernel(u64 s, const u32 *__restrict__ lead, const u32 *__restrict__ sum,
+__global__ __launch_bounds__(256) void lr_place_kernel(u64 s, const LrMin *__restrict__ rec, const LrSum *__restrict__ sh,
                                                        const u32 *__restrict__ dist, const u32 *__restrict__ min_dist,
                                                        const u32 *__restrict__ end_by_leader, u32 *__restrict__ opos,
                                                        u32 *__restrict__ wrap_at, u32 *__restrict__ cyc_len)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
     if (v >= s) return;
-    const u32 l = lead[v];
-    const u32 L = sum[l];
+    const u32 l = rec[v].x;
+    const u32 L = sh[l].x;
     const u32 dm = min_dist[l];
     const u32 d = dist[v];
     const u32 t = d >= dm ? d - dm : d + L - dm;     // distance of v's splitter from the cycle's smallest element
@@ -547,8 +563,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     u32 *LF = arena_array<u32>(ctx, n);
     u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
     void *scan_temp = arena_alloc(ctx, scan_temp_bytes(n));
-    u32 *node[20];
-    for (int i = 0; i < 20; i++) node[i] = arena_array<u32>(ctx, node_cap);
+    u32 *node[12];
+    for (int i = 0; i < 12; i++) node[i] = arena_array<u32>(ctx, node_cap);
+    LrMin *lrmin[2] = {arena_array<LrMin>(ctx, node_cap), arena_array<LrMin>(ctx, node_cap)};
+    LrSum *lrsum[2] = {arena_array<LrSum>(ctx, node_cap), arena_array<LrSum>(ctx, node_cap)};
     CycleRec *d_recs = (CycleRec *)arena_alloc(ctx, node_cap * sizeof(CycleRec));
     u8 *seg = arena_array<u8>(ctx, node_cap * slot);
     const bool bytemark = mark == MARK_BYTEMAP;
@@ -558,34 +576,25 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     u32 *chunk_fill = mark == MARK_LOG ? arena_array<u32>(ctx, log_chunks) : nullptr;
     u32 *bucket_data = mark == MARK_LOG ? arena_array<u32>(ctx, (u64)nbuckets << IDX_RANGE_LOG2) : nullptr;
     u32 *bucket_fill = mark == MARK_LOG ? arena_array<u32>(ctx, (u64)IDX_MAX_BUCKETS * IDX_FILL_STRIDE) : nullptr;
-    if (!LF || !tile_hist || !scan_temp || !node[19] || !d_recs || !seg || (bytemark && !marks) ||
+    if (!LF || !tile_hist || !scan_temp || !node[11] || !lrmin[1] || !lrsum[1] || !d_recs || !seg || (bytemark && !marks) ||
         (mark == MARK_LOG && (!idxlog || !chunk_fill || !bucket_data || !bucket_fill)))
         return BWTS_E_NOMEM;
     if (bytemark) HIPC(hipMemsetAsync(marks, 0, n, ctx->stream));
     u32 *nxt = node[0], *seglen = node[1], *segmin = node[2], *segoff = node[3];
     u32 *d_opos = node[4], *d_wrap = node[5], *d_clen = node[6];
-    u32 *lead[2] = {node[7], node[8]}, *cmin[2] = {node[9], node[10]}, *hop[2] = {node[11], node[12]};
-    u32 *sum[2] = {node[13], node[14]}, *dist = node[15], *min_dist = node[16], *end_by_leader = node[17];
-    u32 *tmp_idx = node[18], *tmp_val = node[19];
+    u32 *dist = node[7], *min_dist = node[8], *end_by_leader = node[9];
+    u32 *tmp_idx = node[10], *tmp_val = node[11];
 
-    // symbol boundaries C[0..256] on the host (unbwts.c:38-43)
-    BWTS_TRY(byte_histogram_device(ctx, d_in, n, ctx->d_small + SMI_HIST));
-    BWTS_TRY(read_small(ctx, SMI_HIST, 256));
-    u64 *hC = ctx->h_small + 1024;
-    {
-        u64 acc = 0;
-        for (int c = 0; c < 256; c++) { hC[c] = acc; acc += ctx->h_small[SMI_HIST + c]; }
-        hC[256] = acc;
-        if (acc != n) return BWTS_E_INTERNAL;
-    }
+    u64 *hC = ctx->h_small + 1024;          // symbol boundaries C[0..256] (unbwts.c:38-43); filled below
     u64 *dC = ctx->d_small + 1024;
-    HIPC(hipMemcpyAsync(dC, hC, 257 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
 
     // stable LF map (unbwts.c:50-52)
     {
         SpanGuard sg(ctx, BWTS_K_LF_BUILD, n, 5 * n);
         lf_hist_kernel<<<dim3((unsigned)tiles), dim3(LF_THREADS), 0, ctx->stream>>>(d_in, n, tile_hist);
         BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, scan_temp));
+        // the scanned table's first row is C itself: no separate histogram sweep, no host round trip before the walk
+        ctab_from_tiles_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(tile_hist, n, dC);
         lf_rank_kernel<<<dim3((unsigned)tiles), dim3(LF_THREADS), 0, ctx->stream>>>(d_in, n, tile_hist, LF);
         HIPC(hipGetLastError());
     }
@@ -612,6 +621,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         HIPC(hipGetLastError());
     }
     // virtual nodes join the reduced list: its size is only known now
+    BWTS_TRY(read_small(ctx, 1024, 257));      // C for the host-side steps below
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
 #ifdef WALK_PROFILE
     {
@@ -653,24 +663,18 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
 
     // reduced-list ranking on the device
     const int R = [&] { int b = 0; for (u64 x = s_all; x; x >>= 1) b++; return b; }();   // 2^R > s >= any cycle's node count
-    int cur = 0;
+    int cur = 0, sc = 0;
     {
         SpanGuard sg(ctx, BWTS_K_LISTRANK, s_all, 0);
         const int gb = grid1(s_all);
-        lr_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nxt, segmin, lead[0], cmin[0], hop[0]);
+        lr_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nxt, segmin, lrmin[0]);
         for (int r = 0; r < R; r++, cur ^= 1)
-            lr_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, lead[cur], cmin[cur], hop[cur], lead[cur ^ 1], cmin[cur ^ 1], hop[cur ^ 1]);
-        u32 *leadf = lead[cur], *cminf = cmin[cur];
-        int sc = 0;
-        lr_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nxt, seglen, leadf, sum[0], hop[0]);
-        int hc = 0;
-        u32 *hopb[2] = {hop[0], hop[1]};
-        for (int r = 0; r < R; r++, sc ^= 1, hc ^= 1)
-            lr_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, sum[sc], hopb[hc], sum[sc ^ 1], hopb[hc ^ 1]);
-        lr_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, leadf, cminf, sum[sc], segmin, segoff, dist, min_dist, d_recs, ticket + 2);
+            lr_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, lrmin[cur], lrmin[cur ^ 1]);
+        lr_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nxt, seglen, lrmin[cur], lrsum[0]);
+        for (int r = 0; r < R; r++, sc ^= 1)
+            lr_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, lrsum[sc], lrsum[sc ^ 1]);
+        lr_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, lrmin[cur], lrsum[sc], segmin, segoff, dist, min_dist, d_recs, ticket + 2);
         HIPC(hipGetLastError());
-        // keep the final buffers' identities for the placement kernel
-        lead[0] = leadf; sum[0] = sum[sc];
     }
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 4));
     const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
@@ -747,7 +751,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     {
         SpanGuard sg(ctx, BWTS_K_LISTRANK, s_all, 0);
         scatter_u32_kernel<<<dim3(grid1(kc)), dim3(256), 0, ctx->stream>>>(tmp_idx, tmp_val, kc, end_by_leader);
-        lr_place_kernel<<<dim3(grid1(s_all)), dim3(256), 0, ctx->stream>>>(s_all, lead[0], sum[0], dist, min_dist, end_by_leader, d_opos, d_wrap, d_clen);
+        lr_place_kernel<<<dim3(grid1(s_all)), dim3(256), 0, ctx->stream>>>(s_all, lrmin[cur], lrsum[sc], dist, min_dist, end_by_leader, d_opos, d_wrap, d_clen);
         HIPC(hipGetLastError());
     }
 
