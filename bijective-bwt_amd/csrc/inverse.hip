@@ -169,9 +169,14 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                                                           unsigned long long *__restrict__ ticket,
                                                           unsigned long long *__restrict__ vcount,
                                                           unsigned long long *__restrict__ overflow,
-                                                          unsigned long long *__restrict__ chunk_ctr, u32 *__restrict__ chunk_fill, u64 log_chunks)
+                                                          unsigned long long *__restrict__ chunk_ctr, u32 *__restrict__ chunk_fill, u64 log_chunks,
+                                                          u32 nbuckets, u32 *__restrict__ bucket_seen)
 {
     __shared__ u64 Ctab[257];
+    // MARK_LOG: how many indices of each 2^IDX_RANGE_LOG2-range this workgroup visited.  A range that ends up with all of
+    // its indices counted holds nothing unvisited, and its log entries need not be looked at again.
+    __shared__ u32 bseen[MARK == MARK_LOG ? IDX_MAX_BUCKETS : 1];
+    if (MARK == MARK_LOG) for (u32 b = threadIdx.x; b < nbuckets; b += 256) bseen[b] = 0;
     for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
     __syncthreads();
     const u32 gmask = (1u << g) - 1u;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                     lbase = lcur = cid * IDX_CHUNK;
                     lend = lbase + IDX_CHUNK;
                 }
-                if (have) idxlog[lcur + (u64)__popcll(act & lanemask_lt())] = x;
+                if (have) { idxlog[lcur + (u64)__popcll(act & lanemask_lt())] = x; atomicAdd(&bseen[x >> IDX_RANGE_LOG2], 1u); }
                 lcur += na;
             }
         }
@@ -265,6 +270,10 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
         }
     }
     if (MARK == MARK_LOG && lend && lane_id() == 0) chunk_fill[lbase / IDX_CHUNK] = (u32)(lcur - lbase);
+    if (MARK == MARK_LOG) {
+        __syncthreads();                  // every wave leaves the loop (the pool runs dry for all of them)
+        for (u32 b = threadIdx.x; b < nbuckets; b += 256) { const u32 c = bseen[b]; if (c) atomicAdd(&bucket_seen[b], c); }
+    }
 #ifdef WALK_PROFILE
     if (lane_id() == 0) { atomicMax(&prof[2], (unsigned long long)wall_clock64()); atomicMin(&prof[4], (unsigned long long)wall_clock64()); }
 #endif
@@ -322,15 +331,28 @@ __global__ __launch_bounds__(256) void collect_unvisited_kernel(const u32 *__res
 // touches (one global atomic each; the counters sit on separate cache lines), orders the chunk by bucket in LDS and
 // copies it out, so a bucket's share leaves as one contiguous run instead of one request per entry.
 // Step 2: one workgroup per bucket sets a bit per logged index in an LDS bitmap and reports the zero bits.
-static inline size_t bucket_indices_lds_bytes(u32 nbuckets) { return (size_t)IDX_CHUNK * 4 + 2 * (size_t)nbuckets * 4; }
+// Step 0: the walk counted the visited indices of every bucket; only DEFICIENT buckets (count < size) can hold an unvisited
+// index, and only their log entries take part in steps 1 and 2 (natural inputs: a few dozen unvisited elements, so a
+// few percent of the buckets).
+__global__ __launch_bounds__(256) void bucket_deficit_kernel(const u32 *__restrict__ bucket_seen, u32 nbuckets, u64 n, u32 *__restrict__ deficient)
+{
+    const u32 b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbuckets) return;
+    const u64 lo = (u64)b << IDX_RANGE_LOG2;
+    const u64 size = n - lo < (1ull << IDX_RANGE_LOG2) ? n - lo : (1ull << IDX_RANGE_LOG2);
+    deficient[b] = (u64)bucket_seen[b] < size ? 1u : 0u;
+}
+
+static inline size_t bucket_indices_lds_bytes(u32 nbuckets) { return (size_t)IDX_CHUNK * 4 + 3 * (size_t)nbuckets * 4; }
 __global__ __launch_bounds__(IDX_THREADS) void bucket_indices_kernel(const u32 *__restrict__ idxlog, const u32 *__restrict__ chunk_fill,
-                                                                     u32 nbuckets, u32 *__restrict__ bucket_fill,
-                                                                     u32 *__restrict__ bucket_data)
+                                                                     u32 nbuckets, const u32 *__restrict__ deficient,
+                                                                     u32 *__restrict__ bucket_fill, u32 *__restrict__ bucket_data)
 {
     extern __shared__ __attribute__((aligned(16))) u32 idx_lds[];
     u32 *sorted = idx_lds;                    // IDX_CHUNK entries ordered by bucket
     u32 *cnt = idx_lds + IDX_CHUNK;           // per bucket: count, then the fill cursor within `sorted`
     u32 *delta = cnt + nbuckets;              // per bucket: (reserved offset in the bucket) - (start in `sorted`)
+    u32 *defl = delta + nbuckets;             // per bucket: takes part?
     __shared__ u32 scan_sm[IDX_THREADS / 64];
     const int tid = threadIdx.x;
     const u32 clen = chunk_fill[blockIdx.x];
@@ -342,13 +364,15 @@ __global__ __launch_bounds__(IDX_THREADS) void bucket_indices_kernel(const u32 *
         const u32 i = (u32)q * IDX_THREADS + tid;
         x[q] = i < clen ? src[i] : 0u;
     }
-    for (u32 b = tid; b < nbuckets; b += IDX_THREADS) cnt[b] = 0;
+    for (u32 b = tid; b < nbuckets; b += IDX_THREADS) { cnt[b] = 0; defl[b] = deficient[b]; }
     __syncthreads();
+    u32 keep = 0;                             // bit q: entry q exists and its bucket takes part
 #pragma unroll
     for (int q = 0; q < IDX_PER_THREAD; q++)
-        if ((u32)q * IDX_THREADS + tid < clen) atomicAdd(&cnt[x[q] >> IDX_RANGE_LOG2], 1u);
-    __syncthreads();
+        if ((u32)q * IDX_THREADS + tid < clen && defl[x[q] >> IDX_RANGE_LOG2]) { keep |= 1u << q; atomicAdd(&cnt[x[q] >> IDX_RANGE_LOG2], 1u); }
+    if (__syncthreads_or(keep != 0) == 0) return;       // nothing of this chunk lies in a deficient bucket
     // exclusive scan of the counts -> start of each bucket's run in `sorted`; room in the bucket from a global atomic
+    u32 kept = 0;                             // entries of this chunk that take part
     {
         const u32 per = (nbuckets + IDX_THREADS - 1) / IDX_THREADS;      // buckets a thread scans (<= 8)
         u32 c[8], run = 0;
@@ -358,8 +382,7 @@ __global__ __launch_bounds__(IDX_THREADS) void bucket_indices_kernel(const u32 *
             c[j] = (u32)j < per && b < nbuckets ? cnt[b] : 0u;
             run += c[j];
         }
-        u32 tot;
-        u32 exc = block_scan_exclusive<u32, OpAdd, IDX_THREADS / 64>(run, OpAdd(), 0u, scan_sm, &tot);
+        u32 exc = block_scan_exclusive<u32, OpAdd, IDX_THREADS / 64>(run, OpAdd(), 0u, scan_sm, &kept);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const u32 b = (u32)tid * per + j;
@@ -374,20 +397,22 @@ __global__ __launch_bounds__(IDX_THREADS) void bucket_indices_kernel(const u32 *
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < IDX_PER_THREAD; q++)
-        if ((u32)q * IDX_THREADS + tid < clen) sorted[atomicAdd(&cnt[x[q] >> IDX_RANGE_LOG2], 1u)] = x[q];
+        if ((keep >> q) & 1u) sorted[atomicAdd(&cnt[x[q] >> IDX_RANGE_LOG2], 1u)] = x[q];
     __syncthreads();
-    for (u32 i = tid; i < clen; i += IDX_THREADS) {
+    for (u32 i = tid; i < kept; i += IDX_THREADS) {
         const u32 v = sorted[i], b = v >> IDX_RANGE_LOG2;
         bucket_data[((u64)b << IDX_RANGE_LOG2) + (u32)(delta[b] + i)] = v;
     }
 }
 
-__global__ __launch_bounds__(1024) void unvisited_from_buckets_kernel(const u32 *__restrict__ bucket_fill, const u32 *__restrict__ bucket_data,
+__global__ __launch_bounds__(1024) void unvisited_from_buckets_kernel(const u32 *__restrict__ deficient, const u32 *__restrict__ bucket_fill,
+                                                                      const u32 *__restrict__ bucket_data,
                                                                       const u32 *__restrict__ LF, u64 n, u32 *__restrict__ uidx,
                                                                       u32 *__restrict__ ulf, u64 cap, unsigned long long *__restrict__ count)
 {
     extern __shared__ __attribute__((aligned(16))) u32 bm[];      // 2^IDX_RANGE_LOG2 bits = 128 KB (dynamic: above the static limit)
     const u32 b = blockIdx.x;
+    if (!deficient[b]) return;
     for (u32 w = threadIdx.x; w < (1u << IDX_RANGE_LOG2) / 32; w += 1024) bm[w] = 0;
     __syncthreads();
     const u32 fill = bucket_fill[(size_t)b * IDX_FILL_STRIDE];
@@ -576,8 +601,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     u32 *chunk_fill = mark == MARK_LOG ? arena_array<u32>(ctx, log_chunks) : nullptr;
     u32 *bucket_data = mark == MARK_LOG ? arena_array<u32>(ctx, (u64)nbuckets << IDX_RANGE_LOG2) : nullptr;
     u32 *bucket_fill = mark == MARK_LOG ? arena_array<u32>(ctx, (u64)IDX_MAX_BUCKETS * IDX_FILL_STRIDE) : nullptr;
+    u32 *bucket_seen = mark == MARK_LOG ? arena_array<u32>(ctx, 2 * IDX_MAX_BUCKETS) : nullptr;   // counts, then deficit flags
+    u32 *deficient = bucket_seen ? bucket_seen + IDX_MAX_BUCKETS : nullptr;
     if (!LF || !tile_hist || !scan_temp || !node[11] || !lrmin[1] || !lrsum[1] || !d_recs || !seg || (bytemark && !marks) ||
-        (mark == MARK_LOG && (!idxlog || !chunk_fill || !bucket_data || !bucket_fill)))
+        (mark == MARK_LOG && (!idxlog || !chunk_fill || !bucket_data || !bucket_fill || !bucket_seen)))
         return BWTS_E_NOMEM;
     if (bytemark) HIPC(hipMemsetAsync(marks, 0, n, ctx->stream));
     u32 *nxt = node[0], *seglen = node[1], *segmin = node[2], *segoff = node[3];
@@ -606,18 +633,21 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     HIPC(hipMemsetAsync(ticket + 8, 0xff, 2 * sizeof(u64), ctx->stream));
     HIPC(hipMemsetAsync(ticket + 12, 0xff, 1 * sizeof(u64), ctx->stream));
 #endif
-    if (mark == MARK_LOG) HIPC(hipMemsetAsync(chunk_fill, 0, log_chunks * sizeof(u32), ctx->stream));
+    if (mark == MARK_LOG) {
+        HIPC(hipMemsetAsync(chunk_fill, 0, log_chunks * sizeof(u32), ctx->stream));
+        HIPC(hipMemsetAsync(bucket_seen, 0, IDX_MAX_BUCKETS * sizeof(u32), ctx->stream));
+    }
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 6 * n);
         if (mark == MARK_BYTEMAP)
             walk_record_kernel<MARK_BYTEMAP><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, nxt, seglen,
-                                                                                          segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks);
+                                                                                          segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         else if (mark == MARK_SENTINEL)
             walk_record_kernel<MARK_SENTINEL><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, nxt, seglen,
-                                                                                           segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks);
+                                                                                           segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         else
             walk_record_kernel<MARK_LOG><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, nxt, seglen,
-                                                                                      segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks);
+                                                                                      segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         HIPC(hipGetLastError());
     }
     // virtual nodes join the reduced list: its size is only known now
@@ -650,9 +680,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
                                          (int)bucket_indices_lds_bytes(IDX_MAX_BUCKETS)));
                 attr_set = true;
             }
+            bucket_deficit_kernel<<<dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream>>>(bucket_seen, nbuckets, n, deficient);
             bucket_indices_kernel<<<dim3((unsigned)log_chunks), dim3(IDX_THREADS), bucket_indices_lds_bytes(nbuckets), ctx->stream>>>(
-                idxlog, chunk_fill, nbuckets, bucket_fill, bucket_data);
-            unvisited_from_buckets_kernel<<<dim3(nbuckets), dim3(1024), bm_bytes, ctx->stream>>>(bucket_fill, bucket_data, LF, n, uidx, ulf, UNV_CAP,
+                idxlog, chunk_fill, nbuckets, deficient, bucket_fill, bucket_data);
+            unvisited_from_buckets_kernel<<<dim3(nbuckets), dim3(1024), bm_bytes, ctx->stream>>>(deficient, bucket_fill, bucket_data, LF, n, uidx, ulf, UNV_CAP,
                                                                                                 ticket + 1);
         } else if (mark == MARK_BYTEMAP)
             collect_unvisited_kernel<MARK_BYTEMAP><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, UNV_CAP, ticket + 1);
