@@ -1,0 +1,55 @@
+"""Condenses two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) of bench.py into the two JSON files kept
+under profiles/: per-kernel means, and the HBM bytes per launch of the roofline kernel.
+
+    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_dir> [round_tag]
+
+Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are
+reported in KB, and FETCH_SIZE counts half of the coalesced read bytes on gfx950, hence x2.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOFLINE_KERNEL = "radix_scatter_packed_kernel<false, false, true>"
+
+
+def load(path):
+    acc = collections.defaultdict(list)          # kernel -> [(grid, value)]
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
+    return acc
+
+
+def main():
+    fetch, write, out_dir = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    tag = sys.argv[4] if len(sys.argv) > 4 else "r01"
+    allk = {}
+    for name, acc in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+        for k, rows in acc.items():
+            gmax = max(g for g, _ in rows)
+            big = [v for g, v in rows if g == gmax]          # the n-sized launches of this kernel
+            allk.setdefault(k[:120], {})[name] = {"launches_total": len(rows), "n_sized_launches": len(big),
+                                                  "mean_KB_n_sized": sum(big) / len(big)}
+    json.dump(allk, open(os.path.join(out_dir, tag + "_pmc_fetch_write_all_kernels.json"), "w"), indent=1)
+    key = [k for k in allk if k.startswith("void " + ROOFLINE_KERNEL) or k.startswith(ROOFLINE_KERNEL)]
+    if key:
+        f = allk[key[0]]["FETCH_SIZE"]["mean_KB_n_sized"]
+        w = allk[key[0]]["WRITE_SIZE"]["mean_KB_n_sized"]
+        json.dump({
+            "kernel": "radix_scatter_packed_kernel<false,false,true>",
+            "alg_bytes_per_element": 20,
+            "workload": "zipf(2^30, seed 1), n-sized launches of bench.py",
+            "FETCH_SIZE_KB_reported": f, "WRITE_SIZE_KB_reported": w,
+            "correction": "gfx950: FETCH_SIZE reports 1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE as is; units KB",
+            "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024),
+            "collected": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes",
+        }, open(os.path.join(out_dir, tag + "_pmc_traffic_radix_scatter.json"), "w"), indent=1)
+        print("roofline kernel: fetch KB", f, "write KB", w, "-> bytes/launch", int(2 * f * 1024 + w * 1024))
+    else:
+        print("roofline kernel not found in the counter files")
+
+
+if __name__ == "__main__":
+    main()
