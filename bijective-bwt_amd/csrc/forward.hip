@@ -907,6 +907,101 @@ static int sort_space_alloc(bwts_ctx *ctx, u64 n, SortSpace *sp)
     return BWTS_OK;
 }
 
+// ---- dense rank array after round 0, binned -------------------------------------------------------------------------
+// rank[SA[i]] = head(i) is n random 4-byte writes: 24 G/s on this chip, 73-85 G/s when the writes in flight fall into a
+// window of <= 1 MB (tools/micro/window_scatter.hip).  So: (1) partition the pairs (SA[i], head(i)) by destination window
+// -- one tile of RB_CHUNK pairs per workgroup, LDS counts, one global atomic per touched window (counters on separate
+// cache lines), the tile ordered by window in LDS and written out in contiguous runs; (2) scatter window after window,
+// all workgroups in the same few windows at a time.  head(i) comes straight from the round-0 flag words, so the tied
+// elements need no second scatter.  SA is a permutation: every window receives exactly its size.
+#define RB_THREADS 512
+#define RB_PER_THREAD 16
+#define RB_CHUNK (RB_THREADS * RB_PER_THREAD)
+#define RB_MAX_WINDOWS 4096
+#define RB_FILL_STRIDE 32
+#define RB_BLOCKS_PER_WINDOW 64
+static inline size_t rank_partition_lds_bytes(u32 nw) { return (size_t)RB_CHUNK * 8 + 2 * (size_t)nw * 4; }
+
+__global__ __launch_bounds__(RB_THREADS) void rank_partition_kernel(const u32 *__restrict__ SA, u64 n, const u64 *__restrict__ headw,
+                                                                    const u64 *__restrict__ pre, int wlog, u32 nw,
+                                                                    u32 *__restrict__ win_fill, u64 *__restrict__ pairs)
+{
+    extern __shared__ __attribute__((aligned(16))) char rb_lds[];
+    u64 *sorted = (u64 *)rb_lds;                       // RB_CHUNK pairs ordered by window
+    u32 *cnt = (u32 *)(sorted + RB_CHUNK);             // per window: count, then the fill cursor within `sorted`
+    u32 *delta = cnt + nw;                             // per window: (reserved offset in the window) - (start in `sorted`)
+    __shared__ u32 scan_sm[RB_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u64 base = (u64)blockIdx.x * RB_CHUNK;
+    const u32 clen = n - base < RB_CHUNK ? (u32)(n - base) : (u32)RB_CHUNK;
+    u32 x[RB_PER_THREAD], h[RB_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < RB_PER_THREAD; q++) {
+        const u32 e = (u32)q * RB_THREADS + tid;
+        x[q] = e < clen ? SA[base + e] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < RB_PER_THREAD; q++) {
+        // slot i = base + e; its 64-slot word is the same for the whole wave
+        const u64 i = base + (u32)q * RB_THREADS + tid;
+        const u64 w = i >> 6;
+        u64 hm = 0, pr = 0;
+        if (i < n) { hm = headw[w]; pr = pre[w]; }
+        const u64 below = lane == 63 ? hm : hm & ((2ull << lane) - 1ull);
+        h[q] = below ? (u32)((w << 6) + (u64)(63 - __clzll((long long)below))) : (u32)(pr >> 32);
+    }
+    for (u32 b = tid; b < nw; b += RB_THREADS) cnt[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RB_PER_THREAD; q++)
+        if ((u32)q * RB_THREADS + tid < clen) atomicAdd(&cnt[x[q] >> wlog], 1u);
+    __syncthreads();
+    {
+        const u32 per = (nw + RB_THREADS - 1) / RB_THREADS;      // windows a thread scans (<= 8)
+        u32 c[8], run = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 b = (u32)tid * per + j;
+            c[j] = (u32)j < per && b < nw ? cnt[b] : 0u;
+            run += c[j];
+        }
+        u32 tot;
+        u32 exc = block_scan_exclusive<u32, OpAdd, RB_THREADS / 64>(run, OpAdd(), 0u, scan_sm, &tot);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u32 b = (u32)tid * per + j;
+            if ((u32)j < per && b < nw) {
+                const u32 g = c[j] ? atomicAdd(&win_fill[(size_t)b * RB_FILL_STRIDE], c[j]) : 0u;
+                cnt[b] = exc;
+                delta[b] = g - exc;
+                exc += c[j];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RB_PER_THREAD; q++)
+        if ((u32)q * RB_THREADS + tid < clen) ((uint2 *)sorted)[atomicAdd(&cnt[x[q] >> wlog], 1u)] = make_uint2(x[q], h[q]);
+    __syncthreads();
+    for (u32 e = tid; e < clen; e += RB_THREADS) {
+        const uint2 v = ((const uint2 *)sorted)[e];
+        const u32 b = v.x >> wlog;
+        ((uint2 *)pairs)[((u64)b << wlog) + (u32)(delta[b] + e)] = v;
+    }
+}
+
+// window b is written by RB_BLOCKS_PER_WINDOW consecutive workgroups, so the workgroups in flight share a few windows
+__global__ __launch_bounds__(256) void rank_scatter_pairs_kernel(const u64 *__restrict__ pairs, const u32 *__restrict__ win_fill, int wlog,
+                                                                 u32 *__restrict__ rank)
+{
+    const u32 b = blockIdx.x / RB_BLOCKS_PER_WINDOW, s = blockIdx.x % RB_BLOCKS_PER_WINDOW;
+    const u32 fill = win_fill[(size_t)b * RB_FILL_STRIDE];
+    const u32 per = (fill + RB_BLOCKS_PER_WINDOW - 1) / RB_BLOCKS_PER_WINDOW;
+    const u32 lo = s * per, hi = lo + per < fill ? lo + per : fill;
+    const uint2 *src = (const uint2 *)pairs + ((u64)b << wlog);
+    for (u32 e = lo + threadIdx.x; e < hi; e += 256) { const uint2 v = src[e]; rank[v.x] = v.y; }
+}
+
 struct ActiveList { u32 *idx, *slot, *head; };
 
 static int build_ranks(bwts_ctx *ctx, const u32 *SA, u64 n, const ActiveList &l, u64 a, u32 *rank)
@@ -950,6 +1045,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     cur.head = sp.vals[res ^ 1];
 
     HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
+    const u64 *flag_heads = nullptr, *flag_pre = nullptr;     // set when the round-0 flag words survive outside sp.rank
     static const bool scan_by_keys = [] { const char *e = getenv("BWTS_GROUPSCAN"); return e && !strcmp(e, "keys"); }();
     if (scan_by_keys) {             // the element-wise scan the later rounds use (kept selectable for tests)
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
@@ -958,9 +1054,14 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         BWTS_TRY((device_scan<true, u64>(ctx, n, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
     } else {
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
-        // sp.rank (4n bytes) is not needed before the rounds that follow: flags and word prefixes live there
+        // flags and word prefixes (3 * n/8 bytes): in the carried-byte ping-pong buffers when there are any (free once the
+        // sort is done), else in sp.rank, which is not needed before the rounds that follow
         const u64 words = (n + 63) / 64;
-        u64 *headw = (u64 *)sp.rank, *keepw = headw + words, *pre = keepw + words;      // 3 * n/8 bytes
+        u64 *headw = (u64 *)sp.rank, *keepw = headw + words, *pre = keepw + words;
+        if (sp.carry_buf[0] && sp.carry_buf[1] && n >= 4096) {
+            headw = (u64 *)sp.carry_buf[0]; keepw = headw + words; pre = (u64 *)sp.carry_buf[1];
+            flag_heads = headw; flag_pre = pre;
+        }
         u64 waves = (words + GF_WORDS - 1) / GF_WORDS;
         unsigned blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
         group_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(K0, n, headw, keepw);
@@ -1020,7 +1121,28 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             if (mr == 0) HIPC(hipMemcpyAsync(trank, scratch, a * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
             HIPC(hipGetLastError());
         } else {
-            BWTS_TRY(build_ranks(ctx, SA, n, cur, a, sp.rank));
+            static const bool plain_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
+            if (flag_heads && n >= (1ull << 22) && !plain_build) {
+                // binned: pairs go through the sorted keys' buffer (not needed without the sparse map), counters through the tile table
+                SpanGuard g(ctx, BWTS_K_RERANK, n, 28 * n);
+                int wlog = bitlen_u64(n - 1) - 12;
+                if (wlog < 18) wlog = 18;
+                const u32 nw = (u32)((n + (1ull << wlog) - 1) >> wlog);
+                u32 *win_fill = sp.tile_hist;
+                HIPC(hipMemsetAsync(win_fill, 0, (size_t)nw * RB_FILL_STRIDE * sizeof(u32), ctx->stream));
+                static bool attr_set = false;
+                if (!attr_set) {
+                    HIPC(hipFuncSetAttribute((const void *)rank_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)rank_partition_lds_bytes(RB_MAX_WINDOWS)));
+                    attr_set = true;
+                }
+                rank_partition_kernel<<<dim3((unsigned)((n + RB_CHUNK - 1) / RB_CHUNK)), dim3(RB_THREADS), rank_partition_lds_bytes(nw), ctx->stream>>>(
+                    SA, n, flag_heads, flag_pre, wlog, nw, win_fill, K0);
+                rank_scatter_pairs_kernel<<<dim3(nw * RB_BLOCKS_PER_WINDOW), dim3(256), 0, ctx->stream>>>(K0, win_fill, wlog, sp.rank);
+                HIPC(hipGetLastError());
+            } else {
+                BWTS_TRY(build_ranks(ctx, SA, n, cur, a, sp.rank));
+            }
             rank_valid = true;
         }
 

@@ -140,6 +140,17 @@ def test_deep_repeats_vs_oracle(ctx):
     assert np.array_equal(ctx.inverse(y), x)
 
 
+def test_dense_ties_large_vs_oracle(ctx):
+    """n >= 2^22 with most elements tied after round 0: the dense rank array is built by the binned scatter."""
+    block = O.generate("zipf", 1 << 21, 5)
+    x = np.concatenate([block, block, O.generate("zipf", 1000, 6), block[: 1 << 20], block])      # ~7.3 MiB, long repeats
+    y = ctx.forward(x)
+    t = ctx.timings()
+    assert t.active_after_round0 > len(x) // 32 and t.rounds >= 10
+    assert np.array_equal(y, O.forward(x))
+    assert np.array_equal(ctx.inverse(y), x)
+
+
 def test_inverse_many_tiny_cycles(ctx):
     """Theta(n) LF cycles without a splitter: the engine falls back to plain pointer jumping (g = 0)."""
     x = np.sort(O.generate("zipf", 3 << 20, 2))          # sorted bytes: LF is the identity, n cycles of length 1
@@ -282,13 +293,14 @@ def test_cli_end_to_end(tmp_path):
     {"BWTS_EMIT": "gather"},                          # classic bwts[r] = P[sa[r]] gather instead of the carried byte
     {"BWTS_RX_PACK": "0"},                            # round-0 sort on wide (u64, u32, u8) streams instead of packed ones
     {"BWTS_GROUPSCAN": "keys"},                       # round-0 group scan element-wise over the keys instead of flag words
+    {"BWTS_RANKBUILD": "plain"},                      # dense rank array by two plain scatters instead of the binned one
     {"BWTS_INV_MARK": "sentinel"},                    # inverse marks visited entries in place instead of logging them
     {"BWTS_BYTEMARK": "1"},                           # inverse marks in a byte map (the n = 2^32 fallback)
     {"BWTS_SPLIT_LOG2": "0"},                         # inverse: every element a splitter (plain pointer jumping)
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_alternate_paths(env):
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
-           "-k", "small or mid_size or deep_repeats or reference_unbwts_vectors_through_cabi"]
+           "-k", "small or mid_size or deep_repeats or dense_ties or reference_unbwts_vectors_through_cabi"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env), cwd=ROOT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
 
