@@ -327,6 +327,28 @@ __device__ __forceinline__ u64 factor_end(const u32 *__restrict__ fstart, u64 k,
 
 // ------------------------------------------------------------------------------------
 // round 0: key[p] = first msym symbols of the suffix at p (zero-filled past the end), value = p
+// Round-0 keys in original order.  Wide: one u64 each.  Split: when the packed sort will take them (at most 40 bits,
+// radix_packed_applicable()), low words and fifth bytes go to two arrays -- exactly what the first packed pass reads --
+// so that pass and its histogram sweep read 6 and 4 bytes per element instead of 9 and 8.
+struct KeyStore { u64 *wide; u32 *lo; u8 *hi; };
+__device__ __forceinline__ void ks_store(const KeyStore &ks, u64 i, u64 key)
+{
+    if (ks.wide) ks.wide[i] = key;
+    else { ks.lo[i] = (u32)key; ks.hi[i] = (u8)(key >> 32); }
+}
+__device__ __forceinline__ u64 ks_load(const KeyStore &ks, u64 i)
+{
+    return ks.wide ? ks.wide[i] : ((u64)ks.lo[i] | ((u64)ks.hi[i] << 32));
+}
+static KeyStore key_store_of(u64 *keys0, u64 n, bool split)
+{
+    KeyStore ks;
+    ks.wide = split ? nullptr : keys0;
+    ks.lo = (u32 *)keys0;
+    ks.hi = (u8 *)keys0 + align_up((size_t)n * 4, 256);
+    return ks;
+}
+
 // ------------------------------------------------------------------------------------
 #define KB_THREADS 256
 #define KB_ITEMS   8
@@ -336,7 +358,7 @@ __device__ __forceinline__ u64 factor_end(const u32 *__restrict__ fstart, u64 k,
 // The value array of round 0 is the identity and is never written: the first radix pass uses the element index.
 __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes_g,
                                                                int bits, int msym, int pad_add,
-                                                               u64 *__restrict__ keys, u64 *__restrict__ tile_min /* may be null */)
+                                                               KeyStore keys, u64 *__restrict__ tile_min /* may be null */)
 {
     __shared__ u16 sc[KB_TILE + KB_HALO + 16];
     __shared__ u64 skey[KB_TILE + KB_TILE / 8];     // blocked -> striped transpose (one pad slot per 8)
@@ -396,7 +418,7 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
 #pragma unroll
     for (int j = 0; j < KB_ITEMS; j++) {
         const u32 e = (u32)j * KB_THREADS + tid;
-        if (base + e < end) keys[base + e] = skey[e + (e >> 3)];
+        if (base + e < end) ks_store(keys, base + e, skey[e + (e >> 3)]);
     }
     // smallest key of the tile: the Lyndon candidate search starts from these (same tile size as the scan)
     if (tile_min && tid == 0) {
@@ -464,7 +486,7 @@ __global__ __launch_bounds__(256) void count_prefix_matches_kernel(const u64 *__
 // reservoir's first key_bits bits, and moving to the next position shifts the first symbol's code word out.  Every
 // symbol is looked up once per thread that needs it; no scan, no atomics.  Same outputs as keybuild0_kernel.
 __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab_g,
-                                                                int key_bits, u64 *__restrict__ keys, u64 *__restrict__ tile_min)
+                                                                int key_bits, KeyStore keys, u64 *__restrict__ tile_min)
 {
     __shared__ u64 vtab[256];
     __shared__ __attribute__((aligned(16))) u8 sb[KB_TILE + KB_HALO + 16];
@@ -528,7 +550,7 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
 #pragma unroll
     for (int j = 0; j < KB_ITEMS; j++) {
         const u32 e = (u32)j * KB_THREADS + tid;
-        if (base + e < end) keys[base + e] = skey[e + (e >> 3)];
+        if (base + e < end) ks_store(keys, base + e, skey[e + (e >> 3)]);
     }
     if (tile_min && tid == 0) {
         u64 t = wmin[0];
@@ -539,7 +561,7 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
 
 // keys of the (up to 64) positions in front of each factor end wrap around inside the factor
 __global__ __launch_bounds__(256) void cyclic_patch_vl_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab, int key_bits,
-                                                              const u32 *__restrict__ fstart, u64 k, u64 *__restrict__ keys)
+                                                              const u32 *__restrict__ fstart, u64 k, KeyStore keys)
 {
     const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     if (t >= k * 64) return;
@@ -547,7 +569,7 @@ __global__ __launch_bounds__(256) void cyclic_patch_vl_kernel(const u8 *__restri
     const u64 s = fstart[f], e = factor_end(fstart, k, n, f);
     if (j >= e - s) return;
     const u64 p = e - 1 - j;
-    keys[p] = vl_key_cyclic(T, vtab, key_bits, p, s, e);
+    ks_store(keys, p, vl_key_cyclic(T, vtab, key_bits, p, s, e));
 }
 
 __global__ __launch_bounds__(256) void iota_kernel(u32 *__restrict__ v, u64 n)
@@ -570,7 +592,7 @@ __device__ __forceinline__ u64 cyclic_key(const u8 *__restrict__ T, const u8 *__
 // positions closer than msym to their factor's end wrap around: rewrite their round-0 keys
 __global__ __launch_bounds__(256) void cyclic_patch_kernel(const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes,
                                                            int bits, int msym, const u32 *__restrict__ fstart, u64 k,
-                                                           u64 *__restrict__ keys)
+                                                           KeyStore keys)
 {
     const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     const u64 per = (u64)(msym - 1);
@@ -579,7 +601,7 @@ __global__ __launch_bounds__(256) void cyclic_patch_kernel(const u8 *__restrict_
     const u64 s = fstart[f], e = factor_end(fstart, k, n, f);
     if (j >= e - s) return;
     const u64 p = e - 1 - j;
-    keys[p] = cyclic_key(T, codes, bits, msym, p, s, e);
+    ks_store(keys, p, cyclic_key(T, codes, bits, msym, p, s, e));
 }
 
 // ------------------------------------------------------------------------------------
@@ -886,6 +908,8 @@ struct SortSpace {
     // the round-0 tie list (slots), for patching the carried bytes of elements that later rounds reorder
     const u32 *tie_slots = nullptr;
     u64 tie_count = 0;
+    // the cyclic sort will carry the byte stream (=> the packed passes may apply); keys[0] currently holds split keys
+    bool want_split = false, split_keys = false;
 };
 
 static size_t sort_space_bytes(u64 n)
@@ -1030,6 +1054,8 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     plan.tile_hist = sp.tile_hist; plan.scan_temp = sp.scan_temp;
     plan.sym_src = sp.carry_src; plan.sym_buf[0] = sp.carry_buf[0]; plan.sym_buf[1] = sp.carry_buf[1]; plan.sym_final = sp.carry_out;
     plan.vals_identity = radix_supports_sym();     // keybuild0 writes no value array
+    plan.keys_split = CYCLIC && sp.split_keys && plan.sym_src && plan.vals_identity;
+    if (CYCLIC && sp.split_keys && !plan.keys_split) return BWTS_E_INTERNAL;      // keybuild split the keys for a sort that cannot take them
     if (!plan.vals_identity) {                     // tuning configs without the identity variant: materialise it
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
         iota_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.vals[0], n);
@@ -1197,18 +1223,19 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
 
 static_assert(KB_TILE == SCAN_TILE, "keybuild0's tile minima feed the scan's final sweep");
 
-static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp, u64 *tile_min)
+static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp, u64 *tile_min, bool split)
 {
-    SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + 8 * n);
+    SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + (split ? 5 : 8) * n);
     const u64 blocks = (n + KB_TILE - 1) / KB_TILE;
+    const KeyStore ks = key_store_of(sp.keys[0], n, split);
     if (al.varlen) {
         keybuild0v_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(d_T, n, ctx->d_small + SM_VTAB, al.key_bits,
-                                                                                        sp.keys[0], tile_min);
+                                                                                        ks, tile_min);
         HIPC(hipGetLastError());
         return BWTS_OK;
     }
     keybuild0_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(
-        d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, sp.keys[0], tile_min);
+        d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, ks, tile_min);
     HIPC(hipGetLastError());
     return BWTS_OK;
 }
@@ -1237,7 +1264,7 @@ static int suffix_sort_in(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, bo
     if (n > 0xffffffffull) return BWTS_E_RANGE;
     Alphabet al;
     BWTS_TRY(set_alphabet(ctx, true, n, &al));
-    BWTS_TRY(launch_keybuild0(ctx, d_T, n, al, sp, nullptr));
+    BWTS_TRY(launch_keybuild0(ctx, d_T, n, al, sp, nullptr, false));
     u64 active0 = 0;
     return doubling_sort<false>(ctx, d_T, n, al, nullptr, 0, sp, want_ranks, d_sa, rounds, &active0);
 }
@@ -1290,12 +1317,12 @@ static int lyndon_general(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, u3
 #define LYN_CAND_CAP   65536ull
 #define LYN_WORK_CAP   (64ull << 20)      // bytes compared inside the resolver workgroup before it gives up
 
-struct KeyIn { const u64 *K; __device__ __forceinline__ u64 operator()(u64 i) const { return K[i]; } };
+struct KeyIn { KeyStore K; __device__ __forceinline__ u64 operator()(u64 i) const { return ks_load(K, i); } };
 struct CandOut {
-    const u64 *K; u64 n; int msym; u64 *cand; u64 cap; u64 *counter;
+    KeyStore K; u64 n; int msym; u64 *cand; u64 cap; u64 *counter;
     __device__ __forceinline__ void operator()(u64 i, u64 min_before) const
     {
-        const u64 ki = K[i];
+        const u64 ki = ks_load(K, i);
         const bool c = i == 0 || ki <= min_before;
         const u64 m = __ballot(c);
         if (m == 0) return;
@@ -1405,8 +1432,9 @@ static int lyndon_fast(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, 
         const u64 tiles = scan_tiles(n);
         HIPC(hipMemcpyAsync(sp.scan_temp, tile_min, tiles * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
         BWTS_TRY((device_scan_partials<u64, OpMin>(ctx, tiles, OpMin(), ~0ull, sp.scan_temp)));
-        KeyIn in{sp.keys[0]};
-        CandOut out{sp.keys[0], n, al.varlen ? 64 : al.msym, cand[0], LYN_CAND_CAP, ctx->d_small + CNT_CAND};
+        const KeyStore ks = key_store_of(sp.keys[0], n, sp.split_keys);
+        KeyIn in{ks};
+        CandOut out{ks, n, al.varlen ? 64 : al.msym, cand[0], LYN_CAND_CAP, ctx->d_small + CNT_CAND};
         TileMayHoldCandidate filter{tile_min};
         BWTS_TRY((device_scan_final<false, u64>(ctx, n, in, out, OpMin(), ~0ull, sp.scan_temp, filter)));
     }
@@ -1500,7 +1528,8 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
         if (!tile_min) return BWTS_E_NOMEM;
         SampleScratch ss{d_T, {sp.keys[0], sp.keys[1]}, {sp.vals[0], sp.vals[1]}, sp.tile_hist, sp.scan_temp};
         BWTS_TRY(set_alphabet(ctx, false, n, al, &ss));
-        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, tile_min));
+        sp.split_keys = sp.want_split && radix_packed_applicable(n, al->key_bits);
+        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, tile_min, sp.split_keys));
         BWTS_TRY(lyndon_fast(ctx, d_T, n, *al, sp, tile_min, cand, cvals, fast_starts, k_out, &done));
         if (done) *d_fstart = fast_starts;
         else if (mode == 1) return BWTS_E_INTERNAL;
@@ -1509,20 +1538,22 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
         BWTS_TRY(lyndon_general(ctx, d_T, n, sp, d_fstart, k_out, lyndon_rounds));
         SampleScratch ss{d_T, {sp.keys[0], sp.keys[1]}, {sp.vals[0], sp.vals[1]}, sp.tile_hist, sp.scan_temp};
         BWTS_TRY(set_alphabet(ctx, false, n, al, &ss));
-        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, nullptr));
+        sp.split_keys = sp.want_split && radix_packed_applicable(n, al->key_bits);
+        BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, nullptr, sp.split_keys));
     }
+    const KeyStore ks = key_store_of(sp.keys[0], n, sp.split_keys);
     // wrap the keys of positions near their factor's end
     if (al->varlen) {
         SpanGuard g(ctx, BWTS_K_KEYBUILD, *k_out * 64, 0);
         const u64 threads = *k_out * 64;
         cyclic_patch_vl_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-            d_T, n, ctx->d_small + SM_VTAB, al->key_bits, *d_fstart, *k_out, sp.keys[0]);
+            d_T, n, ctx->d_small + SM_VTAB, al->key_bits, *d_fstart, *k_out, ks);
         HIPC(hipGetLastError());
     } else if (al->msym > 1) {
         SpanGuard g(ctx, BWTS_K_KEYBUILD, *k_out * (u64)(al->msym - 1), 0);
         const u64 threads = *k_out * (u64)(al->msym - 1);
         cyclic_patch_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-            d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al->bits, al->msym, *d_fstart, *k_out, sp.keys[0]);
+            d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al->bits, al->msym, *d_fstart, *k_out, ks);
         HIPC(hipGetLastError());
     }
     return BWTS_OK;
@@ -1607,6 +1638,9 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     u32 *d_fstart = nullptr;
     u64 k = 0;
     u32 lrounds = 0;
+    const char *emit_env = getenv("BWTS_EMIT");      // carry (default) | gather
+    const bool carry = radix_supports_sym() && !(emit_env && !strcmp(emit_env, "gather"));
+    sp.want_split = carry;                           // the byte stream rides round 0 => the packed passes may take split keys
     BWTS_TRY(factors_and_keys(ctx, d_in, n, sp, &al, &d_fstart, &k, &lrounds));
     ctx->tm.factors = k;
     ctx->tm.lyndon_rounds = lrounds;
@@ -1623,8 +1657,6 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
         prevsym_fix_kernel<<<dim3((unsigned)((k + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_in, n, d_fstart, k, P);
         HIPC(hipGetLastError());
     }
-    const char *emit_env = getenv("BWTS_EMIT");      // carry (default) | gather
-    const bool carry = radix_supports_sym() && !(emit_env && !strcmp(emit_env, "gather"));
     if (carry) {
         sp.carry_src = P;
         sp.carry_buf[0] = arena_array<u8>(ctx, n);

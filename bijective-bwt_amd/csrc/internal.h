@@ -101,7 +101,11 @@ struct SortPlan {
     u8 *sym_buf[2] = {nullptr, nullptr};
     u8 *sym_final = nullptr;         // where the last pass leaves the bytes
     bool vals_identity = false;      // vals[0] is not read: the first pass uses value = element index
+    // keys[0] holds the keys split for the packed sort (radix_packed_applicable()): u32 low words at keys[0], one byte
+    // (bits 32..39) per key at (u8 *)keys[0] + align_up(4 m, 256).  Needs sym_src and vals_identity.
+    bool keys_split = false;
 };
+bool radix_packed_applicable(u64 m, int key_bits);   // will radix_sort_pairs run its packed-stream passes for such a sort?
 bool radix_supports_sym(void);       // the byte stream is compiled for the default tile shape only
 u64    radix_tiles(u64 m);
 size_t radix_tile_hist_bytes(u64 m);

@@ -320,8 +320,8 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
 //     val u32   the position
 //     c   u16   key bits 32..39 | carried byte << 8        (HI16)   -- or u8: the carried byte alone (keys <= 32 bits)
 // = 10 (9) bytes, and a histogram sweep reads only the stream that holds its digit (4 or 2 bytes, not 8).
-// The first pass reads the wide keys keybuild wrote (value = index, IDENT) and the last pass writes wide keys again,
-// so everything downstream still sees sorted u64 keys.  Ranking, LDS staging and XCD mapping are those of
+// The first pass reads the keys as keybuild left them for this sort -- low words and fifth bytes in two arrays, value =
+// index -- and the last pass writes wide keys, so everything downstream sees sorted u64 keys.  Ranking, LDS staging and XCD mapping are those of
 // radix_scatter2_kernel; the LDS tile carries the digit's stream on its first trip and the other two on its second.
 template <typename T>
 __global__ __launch_bounds__(512) void radix_hist_packed_kernel(const T *__restrict__ src, u64 m, int shift, u32 *__restrict__ tile_hist)
@@ -353,14 +353,14 @@ __global__ __launch_bounds__(512) void radix_hist_packed_kernel(const T *__restr
 }
 
 struct PackedIO {
-    const u64 *kin_wide; const u8 *sym_in;                 // IN_WIDE
-    const u32 *lo_in; const u32 *val_in; const void *c_in; // !IN_WIDE (c: u16 if HI16 else u8)
+    const u8 *hi_in; const u8 *sym_in;                     // FIRST: key bits 32..39 and the carried byte, one array each
+    const u32 *lo_in; const u32 *val_in; const void *c_in; // lo always; val and c (u16 if HI16 else u8) on the later passes
     u64 *kout_wide; u8 *sym_out;                           // OUT_WIDE
     u32 *lo_out; void *c_out;                              // !OUT_WIDE
     u32 *val_out;
 };
 
-template <bool IN_WIDE, bool OUT_WIDE, bool HI16>
+template <bool FIRST, bool OUT_WIDE, bool HI16>
 __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO io, const u32 *__restrict__ tile_off, u64 m, int shift)
 {
     constexpr int RX_THREADS = 512, RX_ITEMS = 16, RX_WAVES = 8, RX_TILE = 8192;
@@ -396,14 +396,7 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
     constexpr bool DIG_C = HI16 && OUT_WIDE;
     u32 dsrc[RX_ITEMS];
     u32 posp[RX_ITEMS / 2];
-    if (IN_WIDE) {
-        // the wide key as two words: the low one is this pass's digit stream and is loaded now; the high one (its low
-        // byte joins c) is fetched with the carried byte for the second trip -- its lines are still in L2, and holding
-        // it across the ranking costs spills
-        const u32 *klo = (const u32 *)io.kin_wide + 2 * i0;
-#pragma unroll
-        for (int j = 0; j < RX_ITEMS; j++) dsrc[j] = PK_VALID(j) ? klo[j * 128] : ~0u;
-    } else {
+    {
         const u16 *c16 = (const u16 *)io.c_in + i0;
         const u32 *lop = io.lo_in + i0;
 #pragma unroll
@@ -474,19 +467,18 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
     // the other two streams: (lo, val) on the pass that sorts by c, else (val, c); their loads overlap the write-out below
     u32 sa[RX_ITEMS], sb[RX_ITEMS];
     {
-        const u32 *khi = (const u32 *)io.kin_wide + 2 * i0 + 1;      // key bits 32..39 (first pass; value = index, formed when staged)
         const u32 *lop = io.lo_in + i0, *valp = io.val_in + i0;
-        const u8 *sym8 = io.sym_in + i0, *c8 = (const u8 *)io.c_in + i0;
+        const u8 *sym8 = io.sym_in + i0, *hi8 = io.hi_in + i0, *c8 = (const u8 *)io.c_in + i0;
         const u16 *c16 = (const u16 *)io.c_in + i0;
 #pragma unroll
         for (int j = 0; j < RX_ITEMS; j++) {
-            if (IN_WIDE) sa[j] = (HI16 && PK_VALID(j)) ? khi[j * 128] : 0u;
+            if (FIRST) sa[j] = (HI16 && PK_VALID(j)) ? (u32)hi8[j * 64] : 0u;       // key bits 32..39 (value = index, formed when staged)
             else if (DIG_C) sa[j] = PK_VALID(j) ? lop[j * 64] : 0u;
             else sa[j] = PK_VALID(j) ? valp[j * 64] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < RX_ITEMS; j++) {
-            if (IN_WIDE) sb[j] = PK_VALID(j) ? (u32)sym8[j * 64] : 0u;
+            if (FIRST) sb[j] = PK_VALID(j) ? (u32)sym8[j * 64] : 0u;
             else if (DIG_C) sb[j] = PK_VALID(j) ? valp[j * 64] : 0u;
             else sb[j] = PK_VALID(j) ? (HI16 ? (u32)c16[j * 64] : (u32)c8[j * 64]) : 0u;
         }
@@ -522,7 +514,7 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
     // keeps the sixteen indices of the load addresses alive from the top of the kernel and spills them.)
     u32 idx_base = (u32)wave_base + (u32)lane;
     asm volatile("" : "+v"(idx_base));
-    if (IN_WIDE && HI16) {
+    if (FIRST && HI16) {
         // likewise the carried bytes stay raw in their sixteen registers until here: merged into `hi` on arrival they
         // arrive one at a time, each load waiting for the one before (seen in the ISA: 9.3 ms instead of 5 for the pass)
 #pragma unroll
@@ -531,8 +523,8 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const bool valid = PK_VALID(j);
-        const u32 second = (IN_WIDE && HI16) ? (sa[j] | (sb[j] << 8)) : sb[j];       // keys have <= 40 bits: high word < 256
-        const u32 firstw = IN_WIDE ? idx_base + (u32)j * 64u : sa[j];
+        const u32 second = (FIRST && HI16) ? (sa[j] | (sb[j] << 8)) : sb[j];
+        const u32 firstw = FIRST ? idx_base + (u32)j * 64u : sa[j];
         if (valid) ((uint2 *)stage)[POS_GET(j)] = make_uint2(firstw, second);
     }
     __syncthreads();
@@ -572,20 +564,20 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
 #undef PK_VALID
 }
 
-template <bool IN_WIDE, bool OUT_WIDE, bool HI16>
+template <bool FIRST, bool OUT_WIDE, bool HI16>
 static int launch_scatter_packed(bwts_ctx *ctx, u64 tiles, const PackedIO &io, const u32 *tile_off, u64 m, int shift)
 {
     constexpr size_t lds = (size_t)8192 * 9 + 2048 + 64 + (size_t)8 * 512;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPC(hipFuncSetAttribute((const void *)radix_scatter_packed_kernel<IN_WIDE, OUT_WIDE, HI16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPC(hipFuncSetAttribute((const void *)radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    radix_scatter_packed_kernel<IN_WIDE, OUT_WIDE, HI16><<<dim3((unsigned)rx_grid(tiles)), dim3(512), lds, ctx->stream>>>(io, tile_off, m, shift);
+    radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16><<<dim3((unsigned)rx_grid(tiles)), dim3(512), lds, ctx->stream>>>(io, tile_off, m, shift);
     return BWTS_OK;
 }
 
-// round 0 with the byte stream and identity values, keys of 17..40 bits: wide -> packed ... packed -> wide
+// round 0 with the byte stream and identity values, keys of 17..40 bits: split -> packed ... packed -> wide
 template <bool HI16>
 static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int passes, int *result_buf)
 {
@@ -599,14 +591,13 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
         const bool first = p == 0, last = p == passes - 1;
         char *src = (char *)plan.keys[cur], *dst = (char *)plan.keys[cur ^ 1];
         PackedIO io{};
-        io.kin_wide = plan.keys[cur]; io.sym_in = plan.sym_src;
+        io.hi_in = (const u8 *)src + lo_bytes; io.sym_in = plan.sym_src;
         io.lo_in = (const u32 *)src; io.c_in = src + lo_bytes; io.val_in = plan.vals[cur];
         io.kout_wide = plan.keys[cur ^ 1]; io.sym_out = plan.sym_final;
         io.lo_out = (u32 *)dst; io.c_out = dst + lo_bytes; io.val_out = plan.vals[cur ^ 1];
         {
-            SpanGuard g(ctx, BWTS_K_RADIX_HIST, m, (first ? 8 : (HI16 && shift >= 32) ? 2 : 4) * m);
-            if (first) radix_hist_packed_kernel<u64><<<dim3((unsigned)tiles), dim3(512), 0, ctx->stream>>>(plan.keys[cur], m, shift, tile_hist);
-            else if (HI16 && shift >= 32) radix_hist_packed_kernel<u16><<<dim3((unsigned)tiles), dim3(512), 0, ctx->stream>>>((const u16 *)io.c_in, m, 0, tile_hist);
+            SpanGuard g(ctx, BWTS_K_RADIX_HIST, m, ((HI16 && shift >= 32) ? 2 : 4) * m);
+            if (HI16 && shift >= 32) radix_hist_packed_kernel<u16><<<dim3((unsigned)tiles), dim3(512), 0, ctx->stream>>>((const u16 *)io.c_in, m, 0, tile_hist);
             else radix_hist_packed_kernel<u32><<<dim3((unsigned)tiles), dim3(512), 0, ctx->stream>>>(io.lo_in, m, shift, tile_hist);
         }
         {
@@ -614,7 +605,7 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
             BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, plan.scan_temp));
         }
         if (first) {
-            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (9 + pass_bytes / 2) * m);
+            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, ((HI16 ? 6 : 5) + pass_bytes / 2) * m);
             BWTS_TRY((launch_scatter_packed<true, false, HI16>(ctx, tiles, io, tile_hist, m, shift)));
         } else if (last) {
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (pass_bytes / 2 + 13) * m);
@@ -691,6 +682,13 @@ int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp)
 
 bool radix_supports_sym(void) { return rx_config_index() == 0; }
 
+bool radix_packed_applicable(u64 m, int key_bits)
+{
+    static const bool packed_ok = [] { const char *e = getenv("BWTS_RX_PACK"); return !(e && atoi(e) == 0); }();
+    const int passes = ((key_bits < 1 ? 1 : key_bits) + 7) / 8;
+    return packed_ok && rx_config_index() == 0 && passes >= 3 && passes <= 5 && m >= 65536;
+}
+
 int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, int *result_buf)
 {
     int cur = 0;
@@ -702,9 +700,8 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
     const int cfg = rx_config_index();
     u32 *tile_hist = plan.tile_hist;
 
-    // round 0 of the forward transform (byte stream + identity values) with keys of at most 40 bits: packed streams
-    static const bool packed_ok = [] { const char *e = getenv("BWTS_RX_PACK"); return !(e && atoi(e) == 0); }();
-    if (packed_ok && cfg == 0 && plan.sym_src && plan.vals_identity && passes >= 3 && passes <= 5 && m >= 65536) {
+    if (plan.keys_split) {      // round 0 of the forward transform: keybuild left the keys split for the packed passes
+        if (!plan.sym_src || !plan.vals_identity || !radix_packed_applicable(m, key_bits)) return BWTS_E_INTERNAL;
         if (passes == 5) return radix_sort_packed<true>(ctx, plan, m, passes, result_buf);
         return radix_sort_packed<false>(ctx, plan, m, passes, result_buf);
     }
