@@ -129,6 +129,26 @@ def test_mid_size_vs_oracle(ctx, kind, n, seed):
     assert np.array_equal(ctx.inverse(y), x)
 
 
+@pytest.mark.parametrize("kind,n", [("zipf", 65535), ("zipf", 65536), ("dna", 65537), ("uniform256", 73001), ("zipf", (1 << 22) - 1), ("dna", (1 << 22) + 1)])
+def test_threshold_sizes_vs_oracle(ctx, kind, n):
+    """Sizes on either side of the engine's path switches (packed round-0 sort from 65536, binned rank build from 2^22)."""
+    x = O.generate(kind, n, 21)
+    y = ctx.forward(x)
+    assert np.array_equal(y, O.forward(x))
+    assert np.array_equal(ctx.inverse(y), x)
+
+
+def test_dense_ties_at_bin_threshold_vs_oracle(ctx):
+    """Exactly 2^22 bytes, nearly everything tied after round 0: first size the binned dense-rank build takes."""
+    block = O.generate("zipf", 1 << 20, 8)
+    x = np.concatenate([block, block, block, block])
+    assert len(x) == 1 << 22
+    y = ctx.forward(x)
+    assert ctx.timings().active_after_round0 > len(x) // 32
+    assert np.array_equal(y, O.forward(x))
+    assert np.array_equal(ctx.inverse(y), x)
+
+
 def test_deep_repeats_vs_oracle(ctx):
     """Long repeats force many doubling rounds and a large active set (real-text shape)."""
     rng = np.random.default_rng(5)
