@@ -280,7 +280,11 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
 }
 
 // out[end_c - t] = B[LF^t(min_c)] (unbwts.c:73-82): node v's recorded symbols go to out[opos - i], wrapping to the
-// cycle's end once the walk passes the cycle's smallest element.  tpn threads share a node; both sides coalesce.
+// cycle's end once the walk passes the cycle's smallest element.  A thread moves 16 symbols at a time: one aligned
+// 16-byte load from the node's slot, bytes reversed in registers, one 16-byte store (the destination is not aligned in
+// general: the store goes through a packed type, so the compiler picks what the target allows).  The one chunk of a
+// node that straddles the wrap point, and a ragged tail, go byte by byte.
+struct __attribute__((packed, aligned(1))) Unaligned16 { u32 w[4]; };
 __global__ __launch_bounds__(256) void place_segments_kernel(const u8 *__restrict__ seg, u64 nodes, u32 slot, int tpn_log2,
                                                              const u32 *__restrict__ seglen, const u32 *__restrict__ opos,
                                                              const u32 *__restrict__ wrap_at, const u32 *__restrict__ cyc_len,
@@ -292,7 +296,20 @@ __global__ __launch_bounds__(256) void place_segments_kernel(const u8 *__restric
     const u32 sub = (u32)(gid & ((1ull << tpn_log2) - 1ull)), tpn = 1u << tpn_log2;
     const u32 len = seglen[v], o = opos[v], wr = wrap_at[v], L = cyc_len[v];
     const u8 *src = seg + v * slot;
-    for (u32 i = sub; i < len; i += tpn) out[i >= wr ? o - i + L : o - i] = src[i];
+    for (u32 c = sub * 16; c < len; c += tpn * 16) {
+        if (c + 16 <= len && (c + 16 <= wr || c >= wr)) {
+            const uint4 q = *(const uint4 *)(src + c);
+            // symbols c .. c+15 land on out[base - 15 .. base], last symbol first
+            const u64 base = c >= wr ? (u64)o - c + L : (u64)o - c;
+            Unaligned16 r;
+            r.w[0] = __builtin_bswap32(q.w); r.w[1] = __builtin_bswap32(q.z);
+            r.w[2] = __builtin_bswap32(q.y); r.w[3] = __builtin_bswap32(q.x);
+            *(Unaligned16 *)(out + base - 15) = r;
+        } else {
+            const u32 e = c + 16 < len ? c + 16 : len;
+            for (u32 i = c; i < e; i++) out[i >= wr ? (u64)o - i + L : (u64)o - i] = src[i];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -789,7 +806,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     // the recorded segments go to their places in the text (unbwts.c:73-82)
     {
         SpanGuard sg(ctx, BWTS_K_WALK_EMIT, n, 2 * n);
-        int tpn_log2 = g + 2 - 4;                       // ~16 symbols per thread at the expected segment length
+        int tpn_log2 = g - 4;                           // one 16-symbol chunk per thread at the expected segment length (G)
         if (tpn_log2 < 0) tpn_log2 = 0;
         if (tpn_log2 > 8) tpn_log2 = 8;
         const u64 threads = s_all << tpn_log2;
