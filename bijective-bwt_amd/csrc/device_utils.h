@@ -80,15 +80,20 @@ __device__ __forceinline__ T block_scan_exclusive(T v, Op op, T identity, T *sme
     return op(wave_prefix, exc);
 }
 
-// lanes of the wave whose 8-bit digit equals the caller's (restricted to `valid` lanes)
+// lanes of the wave whose 8-bit digit equals the caller's (restricted to `valid` lanes).
+// The radix kernels are VALU-bound and most of their VALU work is this function, so it is written for instruction
+// count: per digit bit, t = 0 / -1 from a sign-extended one-bit field, one compare for the ballot, and on each
+// 32-bit half an XNOR with the ballot (lanes whose bit equals mine) folded in with an AND -- six instructions.
 __device__ __forceinline__ u64 match_digit8(u32 digit, bool valid)
 {
-    u64 peers = __ballot(valid);
+    const u64 vm = __ballot(valid);
+    u32 plo = (u32)vm, phi = (u32)(vm >> 32);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const bool bit = (digit >> b) & 1u;
-        const u64 m = __ballot(bit);
-        peers &= bit ? m : ~m;
+        const u32 t = (u32)__builtin_amdgcn_sbfe((int)digit, (unsigned)b, 1u);      // 0 or ~0
+        const u64 m = __ballot((int)t < 0);                                              // sign test of t itself: no second extract
+        plo &= ~((u32)m ^ t);
+        phi &= ~((u32)(m >> 32) ^ t);
     }
-    return peers;
+    return ((u64)phi << 32) | plo;
 }

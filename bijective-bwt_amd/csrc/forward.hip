@@ -328,26 +328,41 @@ __device__ __forceinline__ u64 factor_end(const u32 *__restrict__ fstart, u64 k,
 // ------------------------------------------------------------------------------------
 // round 0: key[p] = first msym symbols of the suffix at p (zero-filled past the end), value = p
 // Round-0 keys in original order.  Wide: one u64 each.  Split: when the packed sort will take them (at most 40 bits,
-// radix_packed_applicable()), low words and fifth bytes go to two arrays -- exactly what the first packed pass reads --
-// so that pass and its histogram sweep read 6 and 4 bytes per element instead of 9 and 8.
-struct KeyStore { u64 *wide; u32 *lo; u8 *hi; };
-__device__ __forceinline__ void ks_store(const KeyStore &ks, u64 i, u64 key)
+// radix_packed_applicable()), keybuild writes the two streams the packed passes travel with --
+//   lo  u32  key bits 0..31
+//   c   u16  key bits 32..39 | carried byte << 8      (c16)      or  u8: the carried byte alone (keys of <= 32 bits)
+// where the carried byte of position p is T[cprev(p)] (mk_bwts_sa.c:172-188): T[p-1], fixed at factor heads afterwards.
+// The first pass then reads 6 (5) bytes per element like any other pass, and no separate previous-symbol array exists.
+struct KeyStore { u64 *wide; u32 *lo; u8 *c; bool c16; };
+__device__ __forceinline__ void ks_store(const KeyStore &ks, u64 i, u64 key)        // the key only (patches)
 {
     if (ks.wide) ks.wide[i] = key;
-    else { ks.lo[i] = (u32)key; ks.hi[i] = (u8)(key >> 32); }
+    else { ks.lo[i] = (u32)key; if (ks.c16) ks.c[2 * i] = (u8)(key >> 32); }
+}
+__device__ __forceinline__ void ks_store_with_prev(const KeyStore &ks, u64 i, u64 key, u32 prev)   // key + carried byte (keybuild)
+{
+    if (ks.wide) ks.wide[i] = key;
+    else {
+        ks.lo[i] = (u32)key;
+        if (ks.c16) ((u16 *)ks.c)[i] = (u16)(((u32)(key >> 32) & 255u) | (prev << 8));
+        else ks.c[i] = (u8)prev;
+    }
 }
 __device__ __forceinline__ u64 ks_load(const KeyStore &ks, u64 i)
 {
-    return ks.wide ? ks.wide[i] : ((u64)ks.lo[i] | ((u64)ks.hi[i] << 32));
+    return ks.wide ? ks.wide[i] : ((u64)ks.lo[i] | (ks.c16 ? (u64)ks.c[2 * i] << 32 : 0ull));
 }
-static KeyStore key_store_of(u64 *keys0, u64 n, bool split)
+static KeyStore key_store_of(u64 *keys0, u64 n, bool split, int key_bits)
 {
     KeyStore ks;
     ks.wide = split ? nullptr : keys0;
     ks.lo = (u32 *)keys0;
-    ks.hi = (u8 *)keys0 + align_up((size_t)n * 4, 256);
+    ks.c = (u8 *)keys0 + align_up((size_t)n * 4, 256);
+    ks.c16 = key_bits > 32;
     return ks;
 }
+// the carried byte of a factor's first position is the factor's last byte
+__global__ __launch_bounds__(256) void carried_head_fix_kernel(const u8 *__restrict__ T, u64 n, const u32 *__restrict__ fstart, u64 k, KeyStore ks);
 
 // ------------------------------------------------------------------------------------
 #define KB_THREADS 256
@@ -418,7 +433,11 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
 #pragma unroll
     for (int j = 0; j < KB_ITEMS; j++) {
         const u32 e = (u32)j * KB_THREADS + tid;
-        if (base + e < end) ks_store(keys, base + e, skey[e + (e >> 3)]);
+        if (base + e < end) {
+            const u64 q = base + e;
+            const u32 prev = keys.wide ? 0u : (u32)(q ? T[q - 1] : T[n - 1]);      // the tile's bytes were just read: cache hits
+            ks_store_with_prev(keys, q, skey[e + (e >> 3)], prev);
+        }
     }
     // smallest key of the tile: the Lyndon candidate search starts from these (same tile size as the scan)
     if (tile_min && tid == 0) {
@@ -550,7 +569,11 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
 #pragma unroll
     for (int j = 0; j < KB_ITEMS; j++) {
         const u32 e = (u32)j * KB_THREADS + tid;
-        if (base + e < end) ks_store(keys, base + e, skey[e + (e >> 3)]);
+        if (base + e < end) {
+            const u64 q = base + e;
+            const u32 prev = keys.wide ? 0u : (u32)(q ? T[q - 1] : T[n - 1]);      // the tile's bytes were just read: cache hits
+            ks_store_with_prev(keys, q, skey[e + (e >> 3)], prev);
+        }
     }
     if (tile_min && tid == 0) {
         u64 t = wmin[0];
@@ -1054,7 +1077,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     plan.tile_hist = sp.tile_hist; plan.scan_temp = sp.scan_temp;
     plan.sym_src = sp.carry_src; plan.sym_buf[0] = sp.carry_buf[0]; plan.sym_buf[1] = sp.carry_buf[1]; plan.sym_final = sp.carry_out;
     plan.vals_identity = radix_supports_sym();     // keybuild0 writes no value array
-    plan.keys_split = CYCLIC && sp.split_keys && plan.sym_src && plan.vals_identity;
+    plan.keys_split = CYCLIC && sp.split_keys && plan.sym_final && plan.vals_identity;
     if (CYCLIC && sp.split_keys && !plan.keys_split) return BWTS_E_INTERNAL;      // keybuild split the keys for a sort that cannot take them
     if (!plan.vals_identity) {                     // tuning configs without the identity variant: materialise it
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
@@ -1227,7 +1250,7 @@ static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet 
 {
     SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + (split ? 5 : 8) * n);
     const u64 blocks = (n + KB_TILE - 1) / KB_TILE;
-    const KeyStore ks = key_store_of(sp.keys[0], n, split);
+    const KeyStore ks = key_store_of(sp.keys[0], n, split, al.key_bits);
     if (al.varlen) {
         keybuild0v_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(d_T, n, ctx->d_small + SM_VTAB, al.key_bits,
                                                                                         ks, tile_min);
@@ -1432,7 +1455,7 @@ static int lyndon_fast(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, 
         const u64 tiles = scan_tiles(n);
         HIPC(hipMemcpyAsync(sp.scan_temp, tile_min, tiles * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
         BWTS_TRY((device_scan_partials<u64, OpMin>(ctx, tiles, OpMin(), ~0ull, sp.scan_temp)));
-        const KeyStore ks = key_store_of(sp.keys[0], n, sp.split_keys);
+        const KeyStore ks = key_store_of(sp.keys[0], n, sp.split_keys, al.key_bits);
         KeyIn in{ks};
         CandOut out{ks, n, al.varlen ? 64 : al.msym, cand[0], LYN_CAND_CAP, ctx->d_small + CNT_CAND};
         TileMayHoldCandidate filter{tile_min};
@@ -1541,7 +1564,11 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
         sp.split_keys = sp.want_split && radix_packed_applicable(n, al->key_bits);
         BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, nullptr, sp.split_keys));
     }
-    const KeyStore ks = key_store_of(sp.keys[0], n, sp.split_keys);
+    const KeyStore ks = key_store_of(sp.keys[0], n, sp.split_keys, al->key_bits);
+    if (sp.split_keys) {
+        carried_head_fix_kernel<<<dim3((unsigned)((*k_out + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_T, n, *d_fstart, *k_out, ks);
+        HIPC(hipGetLastError());
+    }
     // wrap the keys of positions near their factor's end
     if (al->varlen) {
         SpanGuard g(ctx, BWTS_K_KEYBUILD, *k_out * 64, 0);
@@ -1596,6 +1623,14 @@ __global__ __launch_bounds__(256) void prevsym_fix_kernel(const u8 *__restrict__
     const u64 f = (u64)blockIdx.x * 256 + threadIdx.x;
     if (f < k) P[fstart[f]] = T[factor_end(fstart, k, n, f) - 1];
 }
+__global__ __launch_bounds__(256) void carried_head_fix_kernel(const u8 *__restrict__ T, u64 n, const u32 *__restrict__ fstart, u64 k, KeyStore ks)
+{
+    const u64 f = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (f >= k) return;
+    const u64 p = fstart[f];
+    const u8 last = T[factor_end(fstart, k, n, f) - 1];
+    if (ks.c16) ks.c[2 * p + 1] = last; else ks.c[p] = last;
+}
 __global__ __launch_bounds__(256) void emit_kernel(const u32 *__restrict__ SA, const u8 *__restrict__ P, u64 n, u8 *__restrict__ out)
 {
     // 8 slots per thread: two 16-byte index loads, eight independent gathers in flight, one packed 8-byte store
@@ -1612,11 +1647,18 @@ __global__ __launch_bounds__(256) void emit_kernel(const u32 *__restrict__ SA, c
 }
 
 // bytes of elements that the later rounds moved: out[slot] = P[sa[slot]]
+// P == nullptr (split keys: no previous-symbol array was built): T[cprev(p)] is looked up through the factor list
 __global__ __launch_bounds__(256) void patch_ties_kernel(const u32 *__restrict__ slots, u64 a, const u32 *__restrict__ SA,
-                                                         const u8 *__restrict__ P, u8 *__restrict__ out)
+                                                         const u8 *__restrict__ P, const u8 *__restrict__ T, u64 n,
+                                                         const u32 *__restrict__ fstart, u64 k, u8 *__restrict__ out)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < a) { const u32 r = slots[i]; out[r] = P[SA[r]]; }
+    if (i >= a) return;
+    const u32 r = slots[i];
+    const u64 p = SA[r];
+    if (P) { out[r] = P[p]; return; }
+    const u64 f = factor_of(fstart, k, p);
+    out[r] = fstart[f] == p ? T[factor_end(fstart, k, n, f) - 1] : T[p - 1];
 }
 
 size_t forward_arena_bytes(u64 n)
@@ -1647,10 +1689,12 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     ctx->tm.key_symbols = (u32)al.msym;
     ctx->tm.key_bits = (u32)al.key_bits;
 
-    // P[p] = T[cprev(p)] (mk_bwts_sa.c:172-188): a factor's head takes the factor's last byte
-    u8 *P = arena_array<u8>(ctx, n);
-    if (!P) return BWTS_E_NOMEM;
-    {
+    // P[p] = T[cprev(p)] (mk_bwts_sa.c:172-188): a factor's head takes the factor's last byte.  With split keys the
+    // byte already travels in the keys' c stream and no array is built.
+    u8 *P = nullptr;
+    if (!sp.split_keys) {
+        P = arena_array<u8>(ctx, n);
+        if (!P) return BWTS_E_NOMEM;
         SpanGuard g(ctx, BWTS_K_OTHER, n, 2 * n);
         u64 blocks = (n / 16 + 255) / 256 + 1; if (blocks > 8192) blocks = 8192;
         prevsym_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(d_in, n, P);
@@ -1677,7 +1721,7 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     if (carry) {
         if (active0) {
             SpanGuard g(ctx, BWTS_K_EMIT, active0, 6 * active0);
-            patch_ties_kernel<<<dim3((unsigned)((active0 + 255) / 256)), dim3(256), 0, ctx->stream>>>(sp.tie_slots, active0, SA, P, d_out);
+            patch_ties_kernel<<<dim3((unsigned)((active0 + 255) / 256)), dim3(256), 0, ctx->stream>>>(sp.tie_slots, active0, SA, P, d_in, n, d_fstart, k, d_out);
         }
     } else {
         SpanGuard g(ctx, BWTS_K_EMIT, n, 6 * n);

@@ -101,8 +101,9 @@ struct SortPlan {
     u8 *sym_buf[2] = {nullptr, nullptr};
     u8 *sym_final = nullptr;         // where the last pass leaves the bytes
     bool vals_identity = false;      // vals[0] is not read: the first pass uses value = element index
-    // keys[0] holds the keys split for the packed sort (radix_packed_applicable()): u32 low words at keys[0], one byte
-    // (bits 32..39) per key at (u8 *)keys[0] + align_up(4 m, 256).  Needs sym_src and vals_identity.
+    // keys[0] holds the keys split for the packed sort (radix_packed_applicable()): u32 low words at keys[0], and at
+    // (u8 *)keys[0] + align_up(4 m, 256) the c stream: u16 (key bits 32..39 | carried byte << 8) for keys of more than 32
+    // bits, else u8 (the carried byte).  sym_src is not read; needs sym_final and vals_identity.
     bool keys_split = false;
 };
 bool radix_packed_applicable(u64 m, int key_bits);   // will radix_sort_pairs run its packed-stream passes for such a sort?

@@ -320,8 +320,8 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
 //     val u32   the position
 //     c   u16   key bits 32..39 | carried byte << 8        (HI16)   -- or u8: the carried byte alone (keys <= 32 bits)
 // = 10 (9) bytes, and a histogram sweep reads only the stream that holds its digit (4 or 2 bytes, not 8).
-// The first pass reads the keys as keybuild left them for this sort -- low words and fifth bytes in two arrays, value =
-// index -- and the last pass writes wide keys, so everything downstream sees sorted u64 keys.  Ranking, LDS staging and XCD mapping are those of
+// keybuild leaves lo and c in exactly this form (forward.hip, KeyStore), the first pass supplies value = index, and the
+// last pass writes wide keys, so everything downstream sees sorted u64 keys.  Ranking, LDS staging and XCD mapping are those of
 // radix_scatter2_kernel; the LDS tile carries the digit's stream on its first trip and the other two on its second.
 template <typename T>
 __global__ __launch_bounds__(512) void radix_hist_packed_kernel(const T *__restrict__ src, u64 m, int shift, u32 *__restrict__ tile_hist)
@@ -353,8 +353,8 @@ __global__ __launch_bounds__(512) void radix_hist_packed_kernel(const T *__restr
 }
 
 struct PackedIO {
-    const u8 *hi_in; const u8 *sym_in;                     // FIRST: key bits 32..39 and the carried byte, one array each
-    const u32 *lo_in; const u32 *val_in; const void *c_in; // lo always; val and c (u16 if HI16 else u8) on the later passes
+    const u32 *lo_in; const void *c_in;                    // c: u16 if HI16 else u8
+    const u32 *val_in;                                     // not read by the first pass (value = index)
     u64 *kout_wide; u8 *sym_out;                           // OUT_WIDE
     u32 *lo_out; void *c_out;                              // !OUT_WIDE
     u32 *val_out;
@@ -468,18 +468,17 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
     u32 sa[RX_ITEMS], sb[RX_ITEMS];
     {
         const u32 *lop = io.lo_in + i0, *valp = io.val_in + i0;
-        const u8 *sym8 = io.sym_in + i0, *hi8 = io.hi_in + i0, *c8 = (const u8 *)io.c_in + i0;
+        const u8 *c8 = (const u8 *)io.c_in + i0;
         const u16 *c16 = (const u16 *)io.c_in + i0;
 #pragma unroll
         for (int j = 0; j < RX_ITEMS; j++) {
-            if (FIRST) sa[j] = (HI16 && PK_VALID(j)) ? (u32)hi8[j * 64] : 0u;       // key bits 32..39 (value = index, formed when staged)
+            if (FIRST) sa[j] = 0u;                                   // value = index, formed when it is staged
             else if (DIG_C) sa[j] = PK_VALID(j) ? lop[j * 64] : 0u;
             else sa[j] = PK_VALID(j) ? valp[j * 64] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < RX_ITEMS; j++) {
-            if (FIRST) sb[j] = PK_VALID(j) ? (u32)sym8[j * 64] : 0u;
-            else if (DIG_C) sb[j] = PK_VALID(j) ? valp[j * 64] : 0u;
+            if (DIG_C) sb[j] = PK_VALID(j) ? valp[j * 64] : 0u;
             else sb[j] = PK_VALID(j) ? (HI16 ? (u32)c16[j * 64] : (u32)c8[j * 64]) : 0u;
         }
     }
@@ -514,16 +513,10 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
     // keeps the sixteen indices of the load addresses alive from the top of the kernel and spills them.)
     u32 idx_base = (u32)wave_base + (u32)lane;
     asm volatile("" : "+v"(idx_base));
-    if (FIRST && HI16) {
-        // likewise the carried bytes stay raw in their sixteen registers until here: merged into `hi` on arrival they
-        // arrive one at a time, each load waiting for the one before (seen in the ISA: 9.3 ms instead of 5 for the pass)
-#pragma unroll
-        for (int j = 0; j < RX_ITEMS; j++) asm volatile("" : "+v"(sb[j]), "+v"(sa[j]));
-    }
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const bool valid = PK_VALID(j);
-        const u32 second = (FIRST && HI16) ? (sa[j] | (sb[j] << 8)) : sb[j];
+        const u32 second = sb[j];
         const u32 firstw = FIRST ? idx_base + (u32)j * 64u : sa[j];
         if (valid) ((uint2 *)stage)[POS_GET(j)] = make_uint2(firstw, second);
     }
@@ -591,7 +584,6 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
         const bool first = p == 0, last = p == passes - 1;
         char *src = (char *)plan.keys[cur], *dst = (char *)plan.keys[cur ^ 1];
         PackedIO io{};
-        io.hi_in = (const u8 *)src + lo_bytes; io.sym_in = plan.sym_src;
         io.lo_in = (const u32 *)src; io.c_in = src + lo_bytes; io.val_in = plan.vals[cur];
         io.kout_wide = plan.keys[cur ^ 1]; io.sym_out = plan.sym_final;
         io.lo_out = (u32 *)dst; io.c_out = dst + lo_bytes; io.val_out = plan.vals[cur ^ 1];
@@ -605,7 +597,7 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
             BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, plan.scan_temp));
         }
         if (first) {
-            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, ((HI16 ? 6 : 5) + pass_bytes / 2) * m);
+            SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (pass_bytes / 2 - 4 + pass_bytes / 2) * m);
             BWTS_TRY((launch_scatter_packed<true, false, HI16>(ctx, tiles, io, tile_hist, m, shift)));
         } else if (last) {
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (pass_bytes / 2 + 13) * m);
@@ -701,7 +693,7 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
     u32 *tile_hist = plan.tile_hist;
 
     if (plan.keys_split) {      // round 0 of the forward transform: keybuild left the keys split for the packed passes
-        if (!plan.sym_src || !plan.vals_identity || !radix_packed_applicable(m, key_bits)) return BWTS_E_INTERNAL;
+        if (!plan.sym_final || !plan.vals_identity || !radix_packed_applicable(m, key_bits)) return BWTS_E_INTERNAL;
         if (passes == 5) return radix_sort_packed<true>(ctx, plan, m, passes, result_buf);
         return radix_sort_packed<false>(ctx, plan, m, passes, result_buf);
     }
