@@ -379,11 +379,14 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
     __shared__ u64 skey[KB_TILE + KB_TILE / 8];     // blocked -> striped transpose (one pad slot per 8)
     __shared__ u8 codes[256];
     __shared__ u64 wmin[KB_THREADS / 64];
+    __shared__ __attribute__((aligned(16))) u8 sraw[KB_TILE + KB_HALO + 16];     // the tile's raw bytes (split keys: carried byte = T[q - 1])
+    __shared__ u8 before_tile;
 
     const int tid = threadIdx.x;
     const u64 base = (u64)blockIdx.x * KB_TILE;
     const u64 end = base + KB_TILE < n ? base + KB_TILE : n;
     codes[tid] = codes_g[tid];
+    if (tid == 0) before_tile = base ? T[base - 1] : T[n - 1];
     __syncthreads();
     const int key_bits = bits * msym;
     const u64 mask = key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull);
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
         const u64 q0 = base + (u64)c * 16;
         if (vec_ok && q0 + 16 <= n) {
             const uint4 v = *(const uint4 *)(T + q0);
+            *(uint4 *)(sraw + c * 16) = v;
             const u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int a = 0; a < 4; a++)
@@ -405,7 +409,9 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
         } else {
             for (int bb = 0; bb < 16; bb++) {
                 const u64 q = q0 + bb;
-                sc[c * 16 + bb] = q < n ? (u16)((u32)codes[T[q]] + (u32)pad_add) : (u16)0;
+                const u8 t = q < n ? T[q] : (u8)0;
+                sraw[c * 16 + bb] = t;
+                sc[c * 16 + bb] = q < n ? (u16)((u32)codes[t] + (u32)pad_add) : (u16)0;
             }
         }
     }
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
         const u32 e = (u32)j * KB_THREADS + tid;
         if (base + e < end) {
             const u64 q = base + e;
-            const u32 prev = keys.wide ? 0u : (u32)(q ? T[q - 1] : T[n - 1]);      // the tile's bytes were just read: cache hits
+            const u32 prev = e ? (u32)sraw[e - 1] : (u32)before_tile;          // T[q - 1], from the tile already in LDS
             ks_store_with_prev(keys, q, skey[e + (e >> 3)], prev);
         }
     }
@@ -500,23 +506,32 @@ __global__ __launch_bounds__(256) void count_prefix_matches_kernel(const u64 *__
     }
 }
 
-// Round-0 keys from variable-length codes.  A thread owns 8 consecutive positions and keeps a 128-bit reservoir of
-// the code stream that starts at its current position: code words are appended at the tail as needed, the key is the
-// reservoir's first key_bits bits, and moving to the next position shifts the first symbol's code word out.  Every
-// symbol is looked up once per thread that needs it; no scan, no atomics.  Same outputs as keybuild0_kernel.
+// Round-0 keys from variable-length codes.  The tile's code words (tile + halo, KB_SYMS symbols) are laid out once as a
+// bit stream in LDS -- per-thread serial prefix of the code lengths, a workgroup scan for the bit offsets, each word OR-ed
+// in at its offset -- and the key of a position is the stream's first key_bits bits from that position's offset: a
+// 64-bit window out of three stream words.  Symbols past the end of the text have length 0 (zero bits follow).
+// (The first version kept a shifting 128-bit reservoir per thread: 118 VALU instructions per position, 91 % VALU busy.)
+// Same outputs as keybuild0_kernel.
+#define KB_SYMS      (KB_TILE + KB_HALO)                    // 2112
+#define KB_SYM_PER   ((KB_SYMS + KB_THREADS - 1) / KB_THREADS)      // symbols a thread lays out: 9
+#define KB_BS_WORDS  ((KB_SYMS * VL_MAXLEN + 31) / 32 + 4)   // stream words incl. zero padding for the last windows
 __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab_g,
                                                                 int key_bits, KeyStore keys, u64 *__restrict__ tile_min)
 {
     __shared__ u64 vtab[256];
-    __shared__ __attribute__((aligned(16))) u8 sb[KB_TILE + KB_HALO + 16];
-    __shared__ u64 skey[KB_TILE + KB_TILE / 8];
+    __shared__ __attribute__((aligned(16))) u8 sb[KB_SYMS + 16];
+    __shared__ u32 bs[KB_BS_WORDS];                 // bit stream, most significant bit of a word first
+    __shared__ u16 symoff[KB_SYMS + 8];             // bit offset of every symbol's code word
     __shared__ u64 wmin[KB_THREADS / 64];
+    __shared__ u32 scan_sm[KB_THREADS / 64];
+    __shared__ u8 before_tile;                      // T[base - 1]: the carried byte of the tile's first position
 
     const int tid = threadIdx.x;
     const u64 base = (u64)blockIdx.x * KB_TILE;
     const u64 end = base + KB_TILE < n ? base + KB_TILE : n;
     vtab[tid] = vtab_g[tid];
-    const u32 span = KB_TILE + KB_HALO;
+    if (tid == 0) before_tile = base ? T[base - 1] : T[n - 1];
+    const u32 span = KB_SYMS;
     const u64 avail = n - base;                                 // symbols of the text from the tile's start
     const u32 nvalid = avail < span ? (u32)avail : span;
     const bool vec_ok = ((uintptr_t)T & 15) == 0;
@@ -528,57 +543,68 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
             for (int bb = 0; bb < 16; bb++) sb[c * 16 + bb] = q0 + bb < n ? T[q0 + bb] : (u8)0;
         }
     }
+    for (u32 i = tid; i < KB_BS_WORDS; i += KB_THREADS) bs[i] = 0;
     __syncthreads();
-    const u32 o = (u32)tid * KB_ITEMS;
-    u64 lo = ~0ull;
-    if (base + o < end) {
-        u64 rh = 0, rl = 0;          // reservoir: bits [0,64) in rh, [64,128) in rl, most significant first
-        int have = 0;                // valid bits in the reservoir
-        u32 nxt = o;                 // next symbol to append
+
+    // lay out symbols [s0, s0 + KB_SYM_PER)
+    const u32 s0 = (u32)tid * KB_SYM_PER;
+    u32 ent_len[KB_SYM_PER], ent_code[KB_SYM_PER];
+    u32 mine = 0;
 #pragma unroll
-        for (int e = 0; e < KB_ITEMS; e++) {
-            if (base + o + e < end) {
-                // top up: a key needs key_bits <= 64 bits; appended words are at most VL_MAXLEN bits, so 128 suffice
-                while (have < 64 && nxt < nvalid) {
-                    const u64 ent = vtab[sb[nxt++]];
-                    const int l = (int)(ent >> 32);
-                    const u64 c = (u32)ent;
-                    const int at = have;                        // first bit the word occupies
-                    if (at + l <= 64) rh |= c << (64 - at - l);
-                    else if (at >= 64) rl |= c << (128 - at - l);
-                    else { rh |= c >> (at + l - 64); rl |= c << (128 - at - l); }
-                    have += l;
-                }
-                const u64 key = rh >> (64 - key_bits);
-                skey[o + e + ((o + e) >> 3)] = key;
-                lo = key < lo ? key : lo;
-                // drop this position's symbol
-                const int l0 = (int)(vtab[sb[o + e]] >> 32);
-                rh = (rh << l0) | (rl >> (64 - l0));
-                rl <<= l0;
-                have -= l0;
-                if (have < 0) have = 0;                         // past the end of the text: nothing left but zeros
+    for (int i = 0; i < KB_SYM_PER; i++) {
+        const u32 sidx = s0 + i;
+        u64 ent = 0;
+        if (sidx < nvalid) ent = vtab[sb[sidx]];            // past the text (or past the halo): length 0
+        ent_len[i] = (u32)(ent >> 32);
+        ent_code[i] = (u32)ent;
+        mine += ent_len[i];
+    }
+    u32 total;
+    u32 off = block_scan_exclusive<u32, OpAdd, KB_THREADS / 64>(mine, OpAdd(), 0u, scan_sm, &total);
+#pragma unroll
+    for (int i = 0; i < KB_SYM_PER; i++) {
+        const u32 sidx = s0 + i;
+        if (sidx < KB_SYMS) symoff[sidx] = (u16)off;
+        const u32 l = ent_len[i];
+        if (l) {
+            const u32 wd = off >> 5, r = off & 31u;
+            if (r + l <= 32) atomicOr(&bs[wd], ent_code[i] << (32 - r - l));
+            else {
+                atomicOr(&bs[wd], ent_code[i] >> (r + l - 32));
+                atomicOr(&bs[wd + 1], ent_code[i] << (64 - r - l));
             }
+        }
+        off += l;
+    }
+    __syncthreads();
+
+    // keys, lane-consecutive over the tile's positions (any thread can cut any position's window out of the stream):
+    // coalesced stores straight from registers
+    u64 lo = ~0ull;
+#pragma unroll
+    for (int j = 0; j < KB_ITEMS; j++) {
+        const u32 e = (u32)j * KB_THREADS + tid;
+        if (base + e < end) {
+            const u32 bo = symoff[e];
+            const u32 wd = bo >> 5, r = bo & 31u;
+            const u64 hi64 = ((u64)bs[wd] << 32) | (u64)bs[wd + 1];
+            const u64 win = r ? (hi64 << r) | ((u64)bs[wd + 2] >> (32 - r)) : hi64;      // 64 stream bits from bo
+            const u64 key = win >> (64 - key_bits);
+            lo = key < lo ? key : lo;
+            const u32 prev = e ? (u32)sb[e - 1] : (u32)before_tile;            // T[q - 1], from the tile already in LDS
+            ks_store_with_prev(keys, base + e, key, prev);
         }
     }
     if (tile_min) {
         lo = wave_scan_inclusive(lo, OpMin());
         if (lane_id() == 63) wmin[wave_id()] = lo;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < KB_ITEMS; j++) {
-        const u32 e = (u32)j * KB_THREADS + tid;
-        if (base + e < end) {
-            const u64 q = base + e;
-            const u32 prev = keys.wide ? 0u : (u32)(q ? T[q - 1] : T[n - 1]);      // the tile's bytes were just read: cache hits
-            ks_store_with_prev(keys, q, skey[e + (e >> 3)], prev);
+        __syncthreads();
+        // smallest key of the tile: the Lyndon candidate search starts from these (same tile size as the scan)
+        if (tid == 0) {
+            u64 t = wmin[0];
+            for (int w = 1; w < KB_THREADS / 64; w++) t = wmin[w] < t ? wmin[w] : t;
+            tile_min[blockIdx.x] = t;
         }
-    }
-    if (tile_min && tid == 0) {
-        u64 t = wmin[0];
-        for (int w = 1; w < KB_THREADS / 64; w++) t = wmin[w] < t ? wmin[w] : t;
-        tile_min[blockIdx.x] = t;
     }
 }
 
