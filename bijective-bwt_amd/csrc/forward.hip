@@ -484,6 +484,30 @@ __device__ __forceinline__ u64 vl_key_cyclic(const u8 *__restrict__ T, const u64
     return acc;
 }
 
+// same key, for the common case that 16 text bytes from q lie inside the factor: one unaligned 16-byte read, table in LDS
+struct __attribute__((packed, aligned(1))) TextChunk16 { u64 w[2]; };
+__device__ __forceinline__ u64 vl_key_cyclic_fast(const u8 *__restrict__ T, const u64 *vtab_lds, const u64 *__restrict__ vtab_g, int key_bits,
+                                                  u64 q, u64 s, u64 e_)
+{
+    if (q + 16 > e_) return vl_key_cyclic(T, vtab_g, key_bits, q, s, e_);
+    const TextChunk16 ch = *(const TextChunk16 *)(T + q);
+    u64 acc = 0;
+    int filled = 0;
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        if (filled < key_bits) {
+            const u32 sym = (u32)((b < 8 ? ch.w[0] >> (8 * b) : ch.w[1] >> (8 * (b - 8))) & 255u);
+            const u64 e = vtab_lds[sym];
+            const int l = (int)(e >> 32), room = key_bits - filled;
+            const u64 c = (u32)e;
+            if (l <= room) { acc = (acc << l) | c; filled += l; }
+            else { acc = (acc << room) | (c >> (l - room)); filled = key_bits; }
+        }
+    }
+    if (filled < key_bits) return vl_key_cyclic(T, vtab_g, key_bits, q, s, e_);     // codes shorter than 4 bits on average: rare
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void sample_keys_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab, u32 samples,
                                                           u64 *__restrict__ out)
 {
@@ -661,14 +685,85 @@ __global__ __launch_bounds__(256) void cyclic_patch_kernel(const u8 *__restrict_
 // of a position that round 0 left tied comes from a small map: tpos = those positions, sorted; trank = their current
 // ranks, refreshed by every round.  So round 0 never scatters ranks (n random 4-byte writes), and a third or fourth
 // round for a handful of stubborn ties costs a handful of binary searches, not an n-sized rank build.
-__device__ __forceinline__ u64 tied_find(const u32 *__restrict__ tpos, u64 a0, u32 q)
+// pdir (may be null): pdir[k] = first map entry whose position is >= k << psh, pdir[last + 1] = a0
+__device__ __forceinline__ u64 tied_find(const u32 *__restrict__ tpos, u64 a0, u32 q, const u32 *__restrict__ pdir = nullptr, int psh = 0)
 {
     u64 lo = 0, hi = a0;
+    if (pdir) { const u32 k = q >> psh; lo = pdir[k]; hi = pdir[k + 1]; }
     while (lo < hi) {
         const u64 mid = (lo + hi) >> 1;
         if (tpos[mid] < q) lo = mid + 1; else hi = mid;
     }
     return (lo < a0 && tpos[lo] == q) ? lo : ~0ull;
+}
+
+// Rank of a key in the sorted round-0 keys.  A plain binary search over n = 2^30 keys is 30 dependent probes, the last
+// ~14 of them cache misses.  A directory over the keys' top dlog bits (dir[k] = first slot whose key's top bits are >= k,
+// dir[2^dlog] = n) narrows the range to ~n / 2^dlog slots; the keys are close to uniform inside a bucket (entropy-coded
+// symbols), so interpolation lands within a few dozen slots and a gallop from there stays inside two or three cache lines.
+#define K0_DIR_LOG2_MAX 20
+__global__ __launch_bounds__(256) void tpos_directory_kernel(const u32 *__restrict__ tpos, u64 a0, int psh, u64 buckets, u32 *__restrict__ pdir)
+{
+    const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (k > buckets) return;
+    if (k == buckets) { pdir[k] = (u32)a0; return; }
+    const u64 want = k << psh;
+    u64 lo = 0, hi = a0;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if ((u64)tpos[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    pdir[k] = (u32)lo;
+}
+__global__ __launch_bounds__(256) void k0_directory_kernel(const u64 *__restrict__ K0, u64 n, int key_bits, int dlog, u64 *__restrict__ dir)
+{
+    const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (k > (1ull << dlog)) return;
+    if (k == (1ull << dlog)) { dir[k] = n; return; }
+    const u64 want = k << (key_bits - dlog);
+    u64 lo = 0, hi = n;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (K0[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    dir[k] = lo;
+}
+__device__ __forceinline__ u64 k0_lower_bound(const u64 *__restrict__ K0, u64 n, u64 want, const u64 *__restrict__ dir, int dlog, int key_bits)
+{
+    u64 lo = 0, hi = n;
+    if (dir) {
+        const int sh = key_bits - dlog;
+        const u64 k = want >> sh;
+        lo = dir[k]; hi = dir[k + 1];
+        if (lo == hi) return lo;
+        u64 g = lo;
+        if (sh > 0) {
+            const double frac = (double)(want & ((1ull << sh) - 1ull)) / (double)(1ull << sh);
+            g = lo + (u64)(frac * (double)(hi - lo));
+        }
+        if (g >= hi) g = hi - 1;
+        if (K0[g] < want) {                     // the answer lies in (g, hi]
+            lo = g + 1;
+            for (u64 st = 1; lo < hi; st <<= 1) {
+                const u64 p = g + st;
+                if (p >= hi) break;
+                if (K0[p] < want) lo = p + 1; else { hi = p; break; }
+            }
+        } else {                                // the answer lies in [lo, g]
+            hi = g;
+            for (u64 st = 1; lo < hi; st <<= 1) {
+                if (st > g - lo) break;
+                const u64 p = g - st;
+                if (K0[p] < want) { lo = p + 1; break; }
+                hi = p;
+            }
+        }
+    }
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (K0[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
 template <bool CYCLIC>
@@ -677,8 +772,13 @@ __global__ __launch_bounds__(256) void keybuild_sparse_kernel(const u32 *__restr
                                                               int bits, int msym, int pad_add, u64 h, const u64 *__restrict__ K0, int rb,
                                                               const u32 *__restrict__ fstart, u64 k, u64 *__restrict__ keys,
                                                               const u64 *__restrict__ vtab /* variable-length codes, or null */, int key_bits,
-                                                              const u32 *__restrict__ tpos, const u32 *__restrict__ trank, u64 a0)
+                                                              const u32 *__restrict__ tpos, const u32 *__restrict__ trank, u64 a0,
+                                                              const u64 *__restrict__ dir, int dlog,
+                                                              const u32 *__restrict__ pdir, int psh)
 {
+    __shared__ u64 svtab[256];
+    if (vtab) svtab[threadIdx.x] = vtab[threadIdx.x];
+    __syncthreads();
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     if (i >= a) return;
     const u64 p = a_idx[i];
@@ -695,13 +795,13 @@ __global__ __launch_bounds__(256) void keybuild_sparse_kernel(const u32 *__restr
     }
     u64 r = 0;
     if (!past_end) {
-        const u64 j = tied_find(tpos, a0, (u32)q);
+        const u64 j = tied_find(tpos, a0, (u32)q, pdir, psh);
         if (j != ~0ull) {
             r = trank[j];
         } else {
             u64 want;
             if (CYCLIC) {
-                want = vtab ? vl_key_cyclic(T, vtab, key_bits, q, s, e) : cyclic_key(T, codes, bits, msym, q, s, e);
+                want = vtab ? vl_key_cyclic_fast(T, svtab, vtab, key_bits, q, s, e) : cyclic_key(T, codes, bits, msym, q, s, e);
             } else {
                 want = 0;
                 for (int jj = 0; jj < msym; jj++) {
@@ -709,12 +809,7 @@ __global__ __launch_bounds__(256) void keybuild_sparse_kernel(const u32 *__restr
                     want = (want << bits) | (rr < n ? (u64)codes[T[rr]] + (u64)pad_add : 0ull);
                 }
             }
-            u64 lo = 0, hi = n;
-            while (lo < hi) {
-                const u64 mid = (lo + hi) >> 1;
-                if (K0[mid] < want) lo = mid + 1; else hi = mid;
-            }
-            r = lo;
+            r = k0_lower_bound(K0, n, want, dir, dlog, key_bits);
         }
     }
     const u64 r2 = CYCLIC ? r : (past_end ? 0ull : r + 1ull);
@@ -1162,7 +1257,8 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         // aux: two key buffers, one value scratch, two list sets
         char *base = nullptr;
         const size_t e4 = align_up((size_t)a * 4, 256), e8 = align_up((size_t)a * 8, 256);
-        BWTS_TRY(aux_reserve(ctx, 2 * e8 + 9 * e4, &base));
+        const size_t dir_bytes = align_up(((size_t)1 << K0_DIR_LOG2_MAX) * 8 + 8, 256) + align_up(((size_t)1 << K0_DIR_LOG2_MAX) * 4 + 8, 256);
+        BWTS_TRY(aux_reserve(ctx, 2 * e8 + 9 * e4 + dir_bytes, &base));
         u64 *akeys[2] = {(u64 *)base, (u64 *)(base + e8)};
         char *q = base + 2 * e8;
         u32 *scratch = (u32 *)q; q += e4;
@@ -1179,11 +1275,23 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         // few tied elements: sparse rank map; many (real text ties most m-grams): the dense rank array, built once now
         const bool sparse = a <= n / 32;
         u32 *tpos = nullptr, *trank = nullptr;
+        u64 *dir = nullptr;
+        u32 *pdir = nullptr;
+        int dlog = 0, psh = 0;
         const u64 a0 = a;
         if (sparse) {
             SpanGuard g(ctx, BWTS_K_RERANK, a, 24 * a);
             tpos = (u32 *)(base + 2 * e8 + 7 * e4);          // the last two arrays of the aux block
             trank = (u32 *)(base + 2 * e8 + 8 * e4);
+            // directory over the sorted keys' top bits for the rank searches of keybuild_sparse_kernel
+            static const bool no_dir = [] { const char *e = getenv("BWTS_K0DIR"); return e && atoi(e) == 0; }();
+            const int kb = al.key_bits;
+            dlog = kb < K0_DIR_LOG2_MAX ? kb : K0_DIR_LOG2_MAX;
+            if (dlog > bitlen_u64(n)) dlog = bitlen_u64(n);
+            if (!no_dir && dlog >= 8) {
+                dir = (u64 *)(base + 2 * e8 + 9 * e4);
+                k0_directory_kernel<<<dim3((unsigned)(((1ull << dlog) + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(K0, n, kb, dlog, dir);
+            }
             tied_map_keys_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(cur.idx, a, akeys[0]);
             HIPC(hipMemcpyAsync(scratch, cur.head, a * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
             SortPlan mp;
@@ -1194,6 +1302,13 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             BWTS_TRY(radix_sort_pairs(ctx, mp, a, bitlen_u64(n - 1) > 0 ? bitlen_u64(n - 1) : 1, &mr));
             tied_map_finish_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(akeys[mr], a, tpos);
             if (mr == 0) HIPC(hipMemcpyAsync(trank, scratch, a * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+            if (dir) {          // same switch as the key directory: a directory over the map's positions
+                const int pb = bitlen_u64(n - 1);
+                psh = pb > K0_DIR_LOG2_MAX ? pb - K0_DIR_LOG2_MAX : 0;
+                const u64 buckets = ((n - 1) >> psh) + 1;
+                pdir = (u32 *)(base + 2 * e8 + 9 * e4 + align_up(((size_t)1 << K0_DIR_LOG2_MAX) * 8 + 8, 256));
+                tpos_directory_kernel<<<dim3((unsigned)((buckets + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(tpos, a, psh, buckets, pdir);
+            }
             HIPC(hipGetLastError());
         } else {
             static const bool plain_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
@@ -1229,7 +1344,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
                 if (sparse)
                     keybuild_sparse_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
                         cur.idx, cur.head, a, d_T, n, d_codes, al.bits, al.msym, al.pad_add, h, K0, rb, d_fstart, k, akeys[0],
-                        al.varlen ? ctx->d_small + SM_VTAB : nullptr, al.key_bits, tpos, trank, a0);
+                        al.varlen ? ctx->d_small + SM_VTAB : nullptr, al.key_bits, tpos, trank, a0, dir, dlog, pdir, psh);
                 else
                     keybuild_h_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
                         cur.idx, cur.head, a, sp.rank, n, h, rb, d_fstart, k, akeys[0]);
