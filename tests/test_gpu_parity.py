@@ -149,6 +149,40 @@ def test_dense_ties_at_bin_threshold_vs_oracle(ctx):
     assert np.array_equal(ctx.inverse(y), x)
 
 
+def _structured_input(seed):
+    """Random inputs with structure: skewed alphabets of several sizes, noisy periodic text, concatenated repeats."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(66000, 400000))
+    kind = seed % 4
+    sigma = int(rng.choice([2, 3, 4, 16, 64, 256]))
+    if kind == 0:                                   # skewed i.i.d. symbols
+        p = rng.random(sigma) ** 3 + 1e-3
+        x = rng.choice(sigma, size=n, p=p / p.sum()).astype(np.uint8)
+    elif kind == 1:                                 # a short period with sparse noise: deep ties, many equal rotations
+        period = rng.integers(0, sigma, size=int(rng.integers(3, 200)), dtype=np.uint8)
+        x = np.resize(period, n).copy()
+        hits = rng.integers(0, n, size=n // 2000)
+        x[hits] = rng.integers(0, sigma, size=hits.size, dtype=np.uint8)
+    elif kind == 2:                                 # long repeats of a random block, different offsets
+        block = rng.integers(0, sigma, size=n // 5, dtype=np.uint8)
+        parts = [block, block[: len(block) // 2], rng.integers(0, sigma, size=777, dtype=np.uint8), block[len(block) // 3:], block]
+        x = np.concatenate(parts)
+    else:                                           # descending runs: many Lyndon factors
+        x = np.sort(rng.integers(0, sigma, size=n, dtype=np.uint8))[::-1].copy()
+        cut = int(rng.integers(1, n))
+        x = np.concatenate([x[cut:], x[:cut]])
+    return x + np.uint8(rng.integers(0, 256 - sigma + 1))     # anywhere in the byte range
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_structured_random_inputs_vs_oracle(ctx, seed):
+    x = _structured_input(seed)
+    y = ctx.forward(x)
+    assert np.array_equal(y, O.forward(x))
+    assert np.array_equal(ctx.inverse(y), x)
+    assert np.array_equal(ctx.forward(ctx.inverse(x)), x)       # the inverse of arbitrary bytes, and back
+
+
 def test_deep_repeats_vs_oracle(ctx):
     """Long repeats force many doubling rounds and a large active set (real-text shape)."""
     rng = np.random.default_rng(5)
