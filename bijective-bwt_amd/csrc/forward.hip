@@ -51,11 +51,15 @@ static int bitlen_u64(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; 
 // ------------------------------------------------------------------------------------
 // byte histogram (also used by the inverse: unbwts.c:34-36)
 // ------------------------------------------------------------------------------------
+// 16 copies of the bins, picked by the lane id: on skewed text a quarter of a wave's lanes would otherwise hit the same
+// counter in one LDS instruction and serialise
+#define BH_COPIES 16
 __global__ __launch_bounds__(256) void byte_hist_kernel(const u8 *__restrict__ T, u64 n, u64 *__restrict__ hist)
 {
-    __shared__ u32 bins[4][256];
-    const int tid = threadIdx.x, w = tid >> 6;
-    for (int i = tid; i < 1024; i += 256) ((u32 *)bins)[i] = 0;
+    __shared__ u32 bins[BH_COPIES][256];
+    const int tid = threadIdx.x;
+    u32 *mine = bins[tid & (BH_COPIES - 1)];
+    for (int i = tid; i < BH_COPIES * 256; i += 256) ((u32 *)bins)[i] = 0;
     __syncthreads();
     // 16 bytes per thread per step when aligned; tail and head handled bytewise
     const u64 nvec = n / 16;
@@ -68,15 +72,17 @@ __global__ __launch_bounds__(256) void byte_hist_kernel(const u8 *__restrict__ T
 #pragma unroll
             for (int a = 0; a < 4; a++) {
 #pragma unroll
-                for (int b = 0; b < 4; b++) atomicAdd(&bins[w][(ws[a] >> (8 * b)) & 255u], 1u);
+                for (int b = 0; b < 4; b++) atomicAdd(&mine[(ws[a] >> (8 * b)) & 255u], 1u);
             }
         }
-        for (u64 i = nvec * 16 + (u64)blockIdx.x * 256 + tid; i < n; i += (u64)gridDim.x * 256) atomicAdd(&bins[w][T[i]], 1u);
+        for (u64 i = nvec * 16 + (u64)blockIdx.x * 256 + tid; i < n; i += (u64)gridDim.x * 256) atomicAdd(&mine[T[i]], 1u);
     } else {
-        for (u64 i = (u64)blockIdx.x * 256 + tid; i < n; i += (u64)gridDim.x * 256) atomicAdd(&bins[w][T[i]], 1u);
+        for (u64 i = (u64)blockIdx.x * 256 + tid; i < n; i += (u64)gridDim.x * 256) atomicAdd(&mine[T[i]], 1u);
     }
     __syncthreads();
-    const u32 s = bins[0][tid] + bins[1][tid] + bins[2][tid] + bins[3][tid];
+    u32 s = 0;
+#pragma unroll
+    for (int c = 0; c < BH_COPIES; c++) s += bins[c][tid];
     if (s) atomicAdd((unsigned long long *)&hist[tid], (unsigned long long)s);
 }
 
