@@ -32,28 +32,35 @@
 // ------------------------------------------------------------------------------------
 // stable LF map
 // ------------------------------------------------------------------------------------
+// per-tile symbol counts.  The order inside the tile does not matter here: a thread takes 16 consecutive bytes (one
+// 16-byte load when the tile is aligned) and counts into one of 16 lane-interleaved copies of the bins (skewed text would
+// otherwise serialise a wave on its most frequent symbols).
+#define LFH_COPIES 16
 __global__ __launch_bounds__(LF_THREADS) void lf_hist_kernel(const u8 *__restrict__ B, u64 n, u32 *__restrict__ tile_hist)
 {
-    __shared__ u32 bins[LF_WAVES][256];
-    const int tid = threadIdx.x, w = tid >> 6;
-    for (int i = tid; i < LF_WAVES * 256; i += LF_THREADS) ((u32 *)bins)[i] = 0;
+    __shared__ u32 bins[LFH_COPIES][256];
+    const int tid = threadIdx.x;
+    u32 *mine = bins[tid & (LFH_COPIES - 1)];
+    for (int i = tid; i < LFH_COPIES * 256; i += LF_THREADS) ((u32 *)bins)[i] = 0;
     __syncthreads();
     const u64 base = (u64)blockIdx.x * LF_TILE;
-    u32 sy[LF_ITEMS];                     // loads first, LDS atomics after: 16 loads in flight per lane
+    const u64 i0 = base + (u64)tid * LF_ITEMS;
+    static_assert(LF_ITEMS == 16, "one 16-byte load per thread");
+    if (i0 + LF_ITEMS <= n && (((uintptr_t)B + i0) & 15) == 0) {
+        const uint4 q = *(const uint4 *)(B + i0);
+        const u32 ws[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-    for (int j = 0; j < LF_ITEMS; j++) {
-        const u64 i = base + (u64)j * LF_THREADS + tid;
-        sy[j] = i < n ? (u32)B[i] : 0u;
-    }
+        for (int a = 0; a < 4; a++) {
 #pragma unroll
-    for (int j = 0; j < LF_ITEMS; j++) {
-        const u64 i = base + (u64)j * LF_THREADS + tid;
-        if (i < n) atomicAdd(&bins[w][sy[j]], 1u);
+            for (int bb = 0; bb < 4; bb++) atomicAdd(&mine[(ws[a] >> (8 * bb)) & 255u], 1u);
+        }
+    } else {
+        for (int j = 0; j < LF_ITEMS; j++) if (i0 + j < n) atomicAdd(&mine[B[i0 + j]], 1u);
     }
     __syncthreads();
     u32 s = 0;
 #pragma unroll
-    for (int ww = 0; ww < LF_WAVES; ww++) s += bins[ww][tid];
+    for (int c = 0; c < LFH_COPIES; c++) s += bins[c][tid];
     tile_hist[(u64)blockIdx.x * 256 + tid] = s;
 }
 
