@@ -347,7 +347,8 @@ def test_cli_end_to_end(tmp_path):
     {"BWTS_EMIT": "gather"},                          # classic bwts[r] = P[sa[r]] gather instead of the carried byte
     {"BWTS_RX_PACK": "0"},                            # round-0 sort on wide (u64, u32, u8) streams instead of packed ones
     {"BWTS_GROUPSCAN": "keys"},                       # round-0 group scan element-wise over the keys instead of flag words
-    {"BWTS_RANKBUILD": "plain"},                      # dense rank array by two plain scatters instead of the binned one
+    {"BWTS_RANKBUILD": "plain"},
+    {"BWTS_K0DIR": "0"},                              # sparse key builder: plain binary searches, no directories                      # dense rank array by two plain scatters instead of the binned one
     {"BWTS_INV_MARK": "sentinel"},                    # inverse marks visited entries in place instead of logging them
     {"BWTS_BYTEMARK": "1"},                           # inverse marks in a byte map (the n = 2^32 fallback)
     {"BWTS_SPLIT_LOG2": "0"},                         # inverse: every element a splitter (plain pointer jumping)
