@@ -1,15 +1,15 @@
 // inverse.hip -- BWTS inverse transform on the GPU.
 //
 // Replaces the inline core of /root/reference/unbwts.c:31-86:
-//   :34-36  histogram            -> byte_hist_kernel (forward.hip)
-//   :38-43  exclusive scan       -> column scan of the [tile][symbol] table (radix.hip)
-//   :50-52  prev[i]=counts[B[i]]++ (stable LF map) -> lf_hist_kernel + lf_rank_kernel
+//   :34-43  histogram + exclusive scan -> row 0 of the scanned [tile][symbol] table (ctab_from_tiles_kernel)
+//   :50-52  prev[i]=counts[B[i]]++ (stable LF map) -> lf_hist_kernel + column scan (radix.hip) + lf_rank_kernel
 //   :66-86  cycle walk, smallest unvisited index first, text written backwards
 //           -> splitter walk recording every segment's symbols, reduced-list ranking by pointer jumping,
-//              coalesced placement of the recorded segments
-// The reference follows ONE cycle at a time (n dependent loads).  Here every G-th index is a
-// splitter; a lane walks from its splitter to the next one, so ~n/G walks run concurrently, and LF is
-// chased exactly once.  Cycles that contain no splitter are found from the visited marks and resolved separately.
+//              placement of the recorded segments
+// The reference follows ONE cycle at a time (n dependent loads).  Here every G-th index is a splitter; a lane walks
+// from its splitter to the next one, so ~n/G walks run concurrently, and LF is chased exactly once.  Cycles that contain
+// no splitter are found from the walk's index log (or, in the alternative modes, from visited marks) and resolved
+// separately.
 #include "internal.h"
 #include "device_utils.h"
 #include "scan_templ.h"
@@ -26,7 +26,6 @@
 #define LF_VISITED 0xffffffffu     // written over an entry once the walk has read it (LF is chased exactly once)
 
 
-#define SMI_HIST     0
 #define SMI_COUNTERS 320
 
 // ------------------------------------------------------------------------------------

@@ -1,12 +1,16 @@
-// radix.hip -- stable 8-bit LSD radix sort of (u64 key, u32 value) pairs.
+// radix.hip -- stable 8-bit LSD radix sort of (u64 key, u32 value) pairs, with an optional byte stream riding along.
 //
 // This replaces the inside of divsufsort() (call site /root/reference/mk_bwts_sa.c:48):
 // the engine sorts suffixes / rotations by prefix doubling, and every doubling round is
 // an LSD radix sort of packed keys.  One pass = three launches:
-//   radix_hist_kernel     per-tile 256-bin digit histogram (LDS, per-wave private bins)
+//   histogram kernel      per-tile 256-bin digit histogram (LDS, per-wave private bins)
 //   column scan           exclusive scan of the [tile][digit] table in digit-major order
-//   radix_scatter_kernel  per-wave ballot ranking, LDS-staged tile sort, coalesced scatter
-// HBM-bound: algorithmic bytes of the scatter = 2 * (8 + 4) * m per pass.
+//   scatter kernel        per-wave ballot ranking, LDS-staged tile sort, coalesced scatter
+// Two families of pass kernels:
+//   radix_hist_kernel / radix_scatter2_kernel                wide streams: u64 key, u32 value (+ u8 byte); 2*(8+4[+1]) bytes
+//                                                            per element and pass.  Later rounds, keys wider than 40 bits.
+//   radix_hist_packed_kernel / radix_scatter_packed_kernel   round 0 of the forward transform with keys of <= 40 bits:
+//                                                            packed streams, 2*(4+4+2) bytes (see "packed streams" below).
 #include "internal.h"
 #include "device_utils.h"
 #include "scan_templ.h"
