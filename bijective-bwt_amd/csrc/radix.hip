@@ -620,6 +620,87 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
 }
 
 // ------------------------------------------------------------------------------------
+// small sorts: every pass inside one workgroup
+// ------------------------------------------------------------------------------------
+// The late rounds of the doubling sort often hold a few hundred stubborn ties; at 7 launches per pass and 7-8 passes per
+// sort, launch latency is all they cost.  Up to RS_MAX pairs are sorted here in one launch: the pairs live in LDS
+// (ping-pong), a pass ranks with the same ballot matching as the big kernels, a thread owns RS_ITEMS consecutive-by-wave
+// elements, and the per-wave digit counts are scanned by the first 256 threads.
+#define RS_THREADS 1024
+#define RS_WAVES   (RS_THREADS / 64)
+#define RS_ITEMS   4
+#define RS_MAX     (RS_THREADS * RS_ITEMS)
+__global__ __launch_bounds__(RS_THREADS) void radix_sort_small_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
+                                                                      u64 *__restrict__ kout, u32 *__restrict__ vout, u32 m, int passes)
+{
+    __shared__ u64 sk[2][RS_MAX];
+    __shared__ u32 sv[2][RS_MAX];
+    __shared__ u16 whist[RS_WAVES][256];
+    __shared__ u32 dbase[256];
+    __shared__ u32 scan_sm[RS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (u32 i = tid; i < m; i += RS_THREADS) { sk[0][i] = kin[i]; sv[0][i] = vin[i]; }
+    int cur = 0;
+    for (int p = 0; p < passes; p++) {
+        const int shift = 8 * p;
+        for (int i = tid; i < RS_WAVES * 128; i += RS_THREADS) ((u32 *)whist)[i] = 0;
+        __syncthreads();
+        // wave w owns elements [w * 64 * RS_ITEMS, ...), item j of a lane is element base + j * 64 + lane
+        const u32 wbase = (u32)w * (64 * RS_ITEMS);
+        u64 key[RS_ITEMS];
+        u32 val[RS_ITEMS], pos[RS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; j++) {
+            const u32 i = wbase + (u32)j * 64 + lane;
+            key[j] = i < m ? sk[cur][i] : ~0ull;
+            val[j] = i < m ? sv[cur][i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; j++) {
+            const bool valid = wbase + (u32)j * 64 + lane < m;
+            const u32 d = (u32)(key[j] >> shift) & 255u;
+            const u64 peers = match_digit8(d, valid);
+            const u32 before = (u32)__popcll(peers & lanemask_lt());
+            const u32 cnt = (u32)__popcll(peers);
+            const u32 prev = whist[w][d];
+            pos[j] = prev + before;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (valid && before == 0) whist[w][d] = (u16)(prev + cnt);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        __syncthreads();
+        {
+            u32 run = 0;
+            if (tid < 256) {
+#pragma unroll
+                for (int ww = 0; ww < RS_WAVES; ww++) {
+                    const u32 c = whist[ww][tid];
+                    whist[ww][tid] = (u16)run;
+                    run += c;
+                }
+            }
+            u32 total;
+            const u32 exc = block_scan_exclusive<u32, OpAdd, RS_WAVES>(run, OpAdd(), 0u, scan_sm, &total);
+            if (tid < 256) dbase[tid] = exc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; j++) {
+            const bool valid = wbase + (u32)j * 64 + lane < m;
+            const u32 d = (u32)(key[j] >> shift) & 255u;
+            if (valid) {
+                const u32 dst = dbase[d] + whist[w][d] + pos[j];
+                sk[cur ^ 1][dst] = key[j];
+                sv[cur ^ 1][dst] = val[j];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (u32 i = tid; i < m; i += RS_THREADS) { kout[i] = sk[cur][i]; vout[i] = sv[cur][i]; }
+}
+
+// ------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------
 template <int TH, int IT>
@@ -696,6 +777,14 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
     const int cfg = rx_config_index();
     u32 *tile_hist = plan.tile_hist;
 
+    static const bool small_ok = [] { const char *e = getenv("BWTS_RX_SMALL"); return !(e && atoi(e) == 0); }();
+    if (small_ok && m <= RS_MAX && !plan.sym_src && !plan.vals_identity && !plan.keys_split) {
+        SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 24 * m);
+        radix_sort_small_kernel<<<dim3(1), dim3(RS_THREADS), 0, ctx->stream>>>(plan.keys[0], plan.vals[0], plan.keys[1], plan.vals[1], (u32)m, passes);
+        HIPC(hipGetLastError());
+        *result_buf = 1;
+        return BWTS_OK;
+    }
     if (plan.keys_split) {      // round 0 of the forward transform: keybuild left the keys split for the packed passes
         if (!plan.sym_final || !plan.vals_identity || !radix_packed_applicable(m, key_bits)) return BWTS_E_INTERNAL;
         if (passes == 5) return radix_sort_packed<true>(ctx, plan, m, passes, result_buf);
