@@ -43,6 +43,7 @@ struct Alphabet {
     int hstep;      // symbols every key is guaranteed to cover: the step of round 1 (msym, or key_bits / longest code)
     int patch_span; // positions in front of a factor's end whose key wraps around (msym - 1, or 64)
 };
+#define SM_SEGCNT 2560      // 256 words: large-group element counts of seg_small_sort_kernel (spread: one address would serialise)
 #define SM_VTAB 2048        // 256 words: (length << 32) | code of each byte value (variable-length codes)
 #define VL_MAXLEN 24        // longest code the variable-length key builder accepts
 
@@ -1176,6 +1177,99 @@ __global__ __launch_bounds__(256) void rank_scatter_pairs_kernel(const u64 *__re
     for (u32 e = lo + threadIdx.x; e < hi; e += 256) { const uint2 v = src[e]; rank[v.x] = v.y; }
 }
 
+// ---- later rounds: sorting inside groups ------------------------------------------------------------------------------
+// The tied list is ordered by group (heads increase along it), so a round's sort by (head, successor rank) only has to
+// order each group by the rank.  On real text most tied elements sit in small groups (53 MiB of source text: 62 % of all
+// element-rounds in groups of <= 8, the late rounds almost entirely pairs), yet a radix sort of the whole list costs 7 passes.
+// seg_small_sort_kernel finds every element's group extent from the list's head array; the first element of a group of at
+// most SEG_CAP sorts it in registers, in place; elements of larger groups are flagged and counted.  If they are the majority
+// the whole list goes through the radix sort as before; otherwise only they are compacted (scan), radix-sorted
+// and written back to the slots they came from -- the compaction keeps list order, and a sort by (head, rank) keeps groups
+// in list order, so the j-th sorted element belongs to the j-th flagged slot.
+#define SEG_CAP 8
+#define SEG_HALO 8                      // list elements a wave looks at in front of the ones it owns
+#define SEG_OWN  (64 - SEG_HALO - SEG_CAP - 1)      // elements a wave decides: their group's start and end lie inside its 64-lane window
+#define SEG_CE(a, b) do { if (k[a] > k[b]) { const u64 tk = k[a]; k[a] = k[b]; k[b] = tk; const u32 tv = v[a]; v[a] = v[b]; v[b] = tv; } } while (0)
+// A wave looks at 64 consecutive list elements (one coalesced load of their group heads), finds group starts with one
+// __ballot, and decides the SEG_OWN elements in the middle of its window: an element's group start is the highest start
+// bit at or below its lane, the group's end the next start bit above that.  Groups of 2 .. SEG_CAP are sorted in place by
+// their first element; elements of larger groups get big[i] = 1 and are counted (one atomic per wave).
+__global__ __launch_bounds__(256) void seg_small_sort_kernel(const u32 *__restrict__ head, u64 *__restrict__ K, u32 *__restrict__ V, u64 a,
+                                                             u8 *__restrict__ big, u64 *__restrict__ big_count)
+{
+    const int lane = lane_id();
+    const u64 wave = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const u64 own0 = wave * SEG_OWN;                 // first element this wave decides
+    if (own0 >= a) return;
+    const long long e = (long long)own0 - SEG_HALO + lane;        // list element of this lane (may lie outside [0, a))
+    const bool inside = e >= 0 && (u64)e < a;
+    const u32 h = inside ? head[e] : 0u;
+    u32 hp = (u32)__shfl_up((int)h, 1, 64);
+    if (lane == 0) hp = (e > 0 && (u64)(e - 1) < a) ? head[e - 1] : 0u;
+    // a start: first element of the list, or head differs from the predecessor's; elements outside the list count as
+    // starts so that a group never extends over them
+    const bool start = !inside || e == 0 || h != hp;
+    const u64 starts = __ballot(start);
+    const bool owned = inside && lane >= SEG_HALO && lane < SEG_HALO + SEG_OWN;
+    bool is_big = false;
+    u32 sz = 0;
+    int s_lane = 0;
+    if (owned) {
+        const u64 below = lane == 63 ? starts : starts & ((2ull << lane) - 1ull);
+        s_lane = below ? 63 - __clzll((long long)below) : -1;
+        if (s_lane < 0 || lane - s_lane >= SEG_CAP) is_big = true;              // start further back than SEG_CAP - 1 elements
+        else {
+            const u64 above = s_lane == 63 ? 0ull : starts >> (s_lane + 1);
+            const int e_lane = above ? s_lane + 1 + (__ffsll((unsigned long long)above) - 1) : 64;
+            sz = (u32)(e_lane - s_lane);
+            if (sz > SEG_CAP) is_big = true;
+        }
+        big[e] = is_big ? 1 : 0;
+    }
+    const u64 bm = __ballot(owned && is_big);
+    if (bm && lane == 0) atomicAdd((unsigned long long *)&big_count[wave & 255], (unsigned long long)__popcll(bm));
+    if (!owned || is_big || s_lane != lane || sz < 2) return;                   // the group's first element sorts it
+    const u64 i = (u64)e;
+    if (sz == 2) {
+        const u64 k0 = K[i], k1 = K[i + 1];
+        if (k0 > k1) { const u32 v0 = V[i], v1 = V[i + 1]; K[i] = k1; K[i + 1] = k0; V[i] = v1; V[i + 1] = v0; }
+        return;
+    }
+    u64 k[SEG_CAP];
+    u32 v[SEG_CAP];
+#pragma unroll
+    for (int j = 0; j < SEG_CAP; j++) {
+        if ((u32)j < sz) { k[j] = K[i + j]; v[j] = V[i + j]; } else { k[j] = ~0ull; v[j] = 0; }      // padding sorts to the end
+    }
+    // Batcher's odd-even merge sort for 8 (19 compare-exchanges)
+    SEG_CE(0, 1); SEG_CE(2, 3); SEG_CE(4, 5); SEG_CE(6, 7);
+    SEG_CE(0, 2); SEG_CE(1, 3); SEG_CE(4, 6); SEG_CE(5, 7);
+    SEG_CE(1, 2); SEG_CE(5, 6);
+    SEG_CE(0, 4); SEG_CE(1, 5); SEG_CE(2, 6); SEG_CE(3, 7);
+    SEG_CE(2, 4); SEG_CE(3, 5);
+    SEG_CE(1, 2); SEG_CE(3, 4); SEG_CE(5, 6);
+#pragma unroll
+    for (int j = 0; j < SEG_CAP; j++)
+        if ((u32)j < sz) { K[i + j] = k[j]; V[i + j] = v[j]; }
+}
+#undef SEG_CE
+struct SegFlagIn { const u8 *big; __device__ __forceinline__ u32 operator()(u64 i) const { return big[i]; } };
+struct SegBigOut {
+    const u8 *big; const u64 *K; const u32 *V; u64 a; u64 *bk; u32 *bv; u32 *bpos; u64 *count;
+    __device__ __forceinline__ void operator()(u64 i, u32 before) const
+    {
+        const u32 f = big[i];
+        if (f) { bk[before] = K[i]; bv[before] = V[i]; bpos[before] = (u32)i; }
+        if (i + 1 == a) *count = (u64)before + f;
+    }
+};
+__global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restrict__ sk, const u32 *__restrict__ sv, const u32 *__restrict__ bpos,
+                                                            u64 m, u64 *__restrict__ K, u32 *__restrict__ V)
+{
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (j < m) { const u32 p = bpos[j]; K[p] = sk[j]; V[p] = sv[j]; }
+}
+
 struct ActiveList { u32 *idx, *slot, *head; };
 
 static int build_ranks(bwts_ctx *ctx, const u32 *SA, u64 n, const ActiveList &l, u64 a, u32 *rank)
@@ -1264,7 +1358,9 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         char *base = nullptr;
         const size_t e4 = align_up((size_t)a * 4, 256), e8 = align_up((size_t)a * 8, 256);
         const size_t dir_bytes = align_up(((size_t)1 << K0_DIR_LOG2_MAX) * 8 + 8, 256) + align_up(((size_t)1 << K0_DIR_LOG2_MAX) * 4 + 8, 256);
-        BWTS_TRY(aux_reserve(ctx, 2 * e8 + 9 * e4 + dir_bytes, &base));
+        const size_t e1 = align_up((size_t)a, 256);
+        const size_t seg_bytes = e1 + 2 * e8 + 3 * e4;            // flags, compacted keys x2, values x2, slots of the larger groups
+        BWTS_TRY(aux_reserve(ctx, 2 * e8 + 9 * e4 + dir_bytes + seg_bytes, &base));
         u64 *akeys[2] = {(u64 *)base, (u64 *)(base + e8)};
         char *q = base + 2 * e8;
         u32 *scratch = (u32 *)q; q += e4;
@@ -1342,6 +1438,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             rank_valid = true;
         }
 
+        bool seg_skip_next = false;
         for (u64 h = (u64)al.hstep;; h <<= 1) {
             rounds++;
             {
@@ -1356,14 +1453,73 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
                         cur.idx, cur.head, a, sp.rank, n, h, rb, d_fstart, k, akeys[0]);
                 HIPC(hipGetLastError());
             }
-            SortPlan ap;
-            ap.keys[0] = akeys[0]; ap.keys[1] = akeys[1];
-            ap.vals[0] = cur.idx; ap.vals[1] = scratch;
-            ap.tile_hist = sp.tile_hist; ap.scan_temp = sp.scan_temp;
-            int r2 = 0;
-            BWTS_TRY(radix_sort_pairs(ctx, ap, a, round_key_bits, &r2));
-            const u64 *AK = akeys[r2];
-            const u32 *AV = r2 ? scratch : cur.idx;
+            const u64 *AK;
+            const u32 *AV;
+            static const bool seg_ok = [] { const char *e = getenv("BWTS_SEGSORT"); return !(e && atoi(e) == 0); }();
+            // (large groups dominating one round dominate the next one too: then the classification is skipped every other round)
+            const bool seg_probe = !seg_skip_next;
+            seg_skip_next = false;
+            if (seg_ok && a > 4096 && seg_probe) {
+                // groups of <= SEG_CAP in place, the rest through the radix sort (see seg_small_sort_kernel)
+                char *sb = base + 2 * e8 + 9 * e4 + dir_bytes;
+                u8 *big = (u8 *)sb;
+                u64 *bk[2] = {(u64 *)(sb + e1), (u64 *)(sb + e1 + e8)};
+                u32 *bv[2] = {(u32 *)(sb + e1 + 2 * e8), (u32 *)(sb + e1 + 2 * e8 + e4)};
+                u32 *bpos = (u32 *)(sb + e1 + 2 * e8 + 2 * e4);
+                u64 m_big = 0;
+                {
+                    SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
+                    u64 *segcnt = ctx->d_small + SM_SEGCNT;
+                    HIPC(hipMemsetAsync(segcnt, 0, 256 * sizeof(u64), ctx->stream));
+                    const u64 waves = (a + SEG_OWN - 1) / SEG_OWN;
+                    seg_small_sort_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream>>>(cur.head, akeys[0], cur.idx, a, big, segcnt);
+                    HIPC(hipGetLastError());
+                }
+                BWTS_TRY(read_small(ctx, SM_SEGCNT, 256));
+                for (int c = 0; c < 256; c++) m_big += ctx->h_small[SM_SEGCNT + c];
+                if (m_big > a) return BWTS_E_INTERNAL;
+                seg_skip_next = m_big * 4 > a * 3;
+                if (m_big * 2 > a) {
+                    // larger groups hold most of the list: sorting everything costs less than compacting them
+                    SortPlan ap;
+                    ap.keys[0] = akeys[0]; ap.keys[1] = akeys[1];
+                    ap.vals[0] = cur.idx; ap.vals[1] = scratch;
+                    ap.tile_hist = sp.tile_hist; ap.scan_temp = sp.scan_temp;
+                    int r2 = 0;
+                    BWTS_TRY(radix_sort_pairs(ctx, ap, a, round_key_bits, &r2));
+                    AK = akeys[r2];
+                    AV = r2 ? scratch : cur.idx;
+                } else {
+                    if (m_big) {
+                        {
+                            SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
+                            SegFlagIn fin{big};
+                            SegBigOut fout{big, akeys[0], cur.idx, a, bk[0], bv[0], bpos, cnt + 3};
+                            BWTS_TRY((device_scan<false, u32>(ctx, a, fin, fout, OpAdd(), 0u, sp.scan_temp)));
+                        }
+                        SortPlan bp;
+                        bp.keys[0] = bk[0]; bp.keys[1] = bk[1];
+                        bp.vals[0] = bv[0]; bp.vals[1] = bv[1];
+                        bp.tile_hist = sp.tile_hist; bp.scan_temp = sp.scan_temp;
+                        int rbig = 0;
+                        BWTS_TRY(radix_sort_pairs(ctx, bp, m_big, round_key_bits, &rbig));
+                        SpanGuard g(ctx, BWTS_K_RERANK, m_big, 28 * m_big);
+                        seg_writeback_kernel<<<dim3((unsigned)((m_big + 255) / 256)), dim3(256), 0, ctx->stream>>>(bk[rbig], bv[rbig], bpos, m_big, akeys[0], cur.idx);
+                        HIPC(hipGetLastError());
+                    }
+                    AK = akeys[0];
+                    AV = cur.idx;
+                }
+            } else {
+                SortPlan ap;
+                ap.keys[0] = akeys[0]; ap.keys[1] = akeys[1];
+                ap.vals[0] = cur.idx; ap.vals[1] = scratch;
+                ap.tile_hist = sp.tile_hist; ap.scan_temp = sp.scan_temp;
+                int r2 = 0;
+                BWTS_TRY(radix_sort_pairs(ctx, ap, a, round_key_bits, &r2));
+                AK = akeys[r2];
+                AV = r2 ? scratch : cur.idx;
+            }
 
             HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
             {

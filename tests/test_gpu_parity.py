@@ -367,6 +367,7 @@ def test_cli_end_to_end(tmp_path):
     {"BWTS_RX_PACK": "0"},                            # round-0 sort on wide (u64, u32, u8) streams instead of packed ones
     {"BWTS_GROUPSCAN": "keys"},                       # round-0 group scan element-wise over the keys instead of flag words
     {"BWTS_RANKBUILD": "plain"},
+    {"BWTS_SEGSORT": "0"},                            # later rounds: radix sort of the whole tied list instead of sorting small groups in place
     {"BWTS_RX_SMALL": "0"},                           # small sorts through the multi-launch passes instead of the one-workgroup kernel
     {"BWTS_K0DIR": "0"},                              # sparse key builder: plain binary searches, no directories                      # dense rank array by two plain scatters instead of the binned one
     {"BWTS_INV_MARK": "sentinel"},                    # inverse marks visited entries in place instead of logging them
