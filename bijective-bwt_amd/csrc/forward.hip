@@ -914,6 +914,7 @@ struct GroupIn {
 
 struct GroupOut {
     const u32 *S; const u32 *V; u64 a; int rb;     // rb < 0: round 0 (no older groups)
+    const u64 *K;                                   // later rounds: the sorted keys (old head = K[i] >> rb), else nullptr
     u32 *rank;                                      // dense rank array, or nullptr
     const u32 *tpos; u32 *trank; u64 a0;            // sparse rank map (tied positions -> rank), or nullptr
     u32 *SA;
@@ -927,8 +928,10 @@ struct GroupOut {
         const u32 head = (u32)(v >> 32);
         const u32 val = (keep || rank || S) ? V[i] : 0u;     // round 0 touches the suffix array only for tied elements
         const u32 slot = S ? S[i] : (u32)i;
-        if (rank) rank[val] = head;
-        if (tpos) { const u64 j = tied_find(tpos, a0, val); if (j != ~0ull) trank[j] = head; }
+        // an element whose group keeps its first slot keeps its rank: no random write (dense) / map search (sparse) for it
+        const bool moved = !K || (u32)(K[i] >> rb) != head;
+        if (rank && moved) rank[val] = head;
+        if (tpos && moved) { const u64 j = tied_find(tpos, a0, val); if (j != ~0ull) trank[j] = head; }
         if (S) SA[slot] = val;
         if (keep) {
             const u32 dst = (u32)v - 1u;
@@ -1320,7 +1323,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     if (scan_by_keys) {             // the element-wise scan the later rounds use (kept selectable for tests)
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
         GroupIn in{K0, nullptr, n, -1};
-        GroupOut out{nullptr, SA, n, -1, nullptr, nullptr, nullptr, 0, SA, cur.idx, cur.slot, cur.head, cnt + 0, cnt + 1};
+        GroupOut out{nullptr, SA, n, -1, nullptr, nullptr, nullptr, nullptr, 0, SA, cur.idx, cur.slot, cur.head, cnt + 0, cnt + 1};
         BWTS_TRY((device_scan<true, u64>(ctx, n, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
     } else {
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
@@ -1525,7 +1528,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             {
                 SpanGuard g(ctx, BWTS_K_RERANK, a, 24 * a);
                 GroupIn in{AK, cur.slot, a, rb};
-                GroupOut out{cur.slot, AV, a, rb, sparse ? nullptr : sp.rank, tpos, trank, a0, SA,
+                GroupOut out{cur.slot, AV, a, rb, AK, sparse ? nullptr : sp.rank, tpos, trank, a0, SA,
                              sets[nxt].idx, sets[nxt].slot, sets[nxt].head, cnt + 0, cnt + 1};
                 BWTS_TRY((device_scan<true, u64>(ctx, a, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
             }
