@@ -1481,9 +1481,10 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
                 BWTS_TRY(read_small(ctx, SM_SEGCNT, 256));
                 for (int c = 0; c < 256; c++) m_big += ctx->h_small[SM_SEGCNT + c];
                 if (m_big > a) return BWTS_E_INTERNAL;
-                seg_skip_next = m_big * 4 > a * 3;
-                if (m_big * 2 > a) {
-                    // larger groups hold most of the list: sorting everything costs less than compacting them
+                seg_skip_next = m_big * 10 > a * 9;
+                if (m_big * 5 > a * 4) {
+                    // larger groups hold nearly all of the list: sorting everything costs less than compacting them
+                    // (by bytes moved the break-even is near 85 %)
                     SortPlan ap;
                     ap.keys[0] = akeys[0]; ap.keys[1] = akeys[1];
                     ap.vals[0] = cur.idx; ap.vals[1] = scratch;
