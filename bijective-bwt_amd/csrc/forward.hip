@@ -1256,21 +1256,44 @@ __global__ __launch_bounds__(256) void seg_small_sort_kernel(const u32 *__restri
         if ((u32)j < sz) { K[i + j] = k[j]; V[i + j] = v[j]; }
 }
 #undef SEG_CE
-struct SegFlagIn { const u8 *big; __device__ __forceinline__ u32 operator()(u64 i) const { return big[i]; } };
-struct SegBigOut {
-    const u8 *big; const u64 *K; const u32 *V; u64 a; u64 *bk; u32 *bv; u32 *bpos; u64 *count;
-    __device__ __forceinline__ void operator()(u64 i, u32 before) const
+// compaction of the larger groups' elements.  Scan value: low word = flagged elements, high word = flagged groups (their
+// first elements) before the position.  The compacted key carries the group's ordinal among the flagged groups instead of
+// its head slot -- at most m/(SEG_CAP+1) groups, so the radix sort of the compacted list needs fewer key bits (usually a
+// whole pass less); seg_writeback_kernel puts the head back.
+struct SegFlagIn {
+    const u8 *big; const u32 *head;
+    __device__ __forceinline__ u64 operator()(u64 i) const
     {
         const u32 f = big[i];
-        if (f) { bk[before] = K[i]; bv[before] = V[i]; bpos[before] = (u32)i; }
-        if (i + 1 == a) *count = (u64)before + f;
+        const u32 st = f && (i == 0 || head[i] != head[i - 1]) ? 1u : 0u;
+        return ((u64)st << 32) | f;
+    }
+};
+struct SegBigOut {
+    const u8 *big; const u32 *head; const u64 *K; const u32 *V; u64 a; int rb; u64 *bk; u32 *bv; u32 *bpos; u64 *count;
+    __device__ __forceinline__ void operator()(u64 i, u64 before) const
+    {
+        const u32 f = big[i];
+        if (f) {
+            const u32 st = (i == 0 || head[i] != head[i - 1]) ? 1u : 0u;
+            const u64 ord = (before >> 32) + st - 1;                     // groups flagged up to and including this element's, minus one
+            const u32 at = (u32)before;
+            bk[at] = (ord << rb) | (K[i] & ((1ull << rb) - 1ull));
+            bv[at] = V[i];
+            bpos[at] = (u32)i;
+        }
+        if (i + 1 == a) *count = (u64)(u32)before + f;
     }
 };
 __global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restrict__ sk, const u32 *__restrict__ sv, const u32 *__restrict__ bpos,
-                                                            u64 m, u64 *__restrict__ K, u32 *__restrict__ V)
+                                                            u64 m, const u32 *__restrict__ head, int rb, u64 *__restrict__ K, u32 *__restrict__ V)
 {
     const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (j < m) { const u32 p = bpos[j]; K[p] = sk[j]; V[p] = sv[j]; }
+    if (j < m) {
+        const u32 p = bpos[j];
+        K[p] = ((u64)head[p] << rb) | (sk[j] & ((1ull << rb) - 1ull));       // the slot's group (sorting keeps groups in place)
+        V[p] = sv[j];
+    }
 }
 
 struct ActiveList { u32 *idx, *slot, *head; };
@@ -1497,18 +1520,20 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
                     if (m_big) {
                         {
                             SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
-                            SegFlagIn fin{big};
-                            SegBigOut fout{big, akeys[0], cur.idx, a, bk[0], bv[0], bpos, cnt + 3};
-                            BWTS_TRY((device_scan<false, u32>(ctx, a, fin, fout, OpAdd(), 0u, sp.scan_temp)));
+                            SegFlagIn fin{big, cur.head};
+                            SegBigOut fout{big, cur.head, akeys[0], cur.idx, a, rb, bk[0], bv[0], bpos, cnt + 3};
+                            BWTS_TRY((device_scan<false, u64>(ctx, a, fin, fout, OpAdd(), (u64)0, sp.scan_temp)));
                         }
                         SortPlan bp;
                         bp.keys[0] = bk[0]; bp.keys[1] = bk[1];
                         bp.vals[0] = bv[0]; bp.vals[1] = bv[1];
                         bp.tile_hist = sp.tile_hist; bp.scan_temp = sp.scan_temp;
                         int rbig = 0;
-                        BWTS_TRY(radix_sort_pairs(ctx, bp, m_big, round_key_bits, &rbig));
+                        const int big_bits = bitlen_u64(m_big / (SEG_CAP + 1)) + rb;       // ordinals < m_big / (SEG_CAP + 1)
+                        BWTS_TRY(radix_sort_pairs(ctx, bp, m_big, big_bits < round_key_bits ? big_bits : round_key_bits, &rbig));
                         SpanGuard g(ctx, BWTS_K_RERANK, m_big, 28 * m_big);
-                        seg_writeback_kernel<<<dim3((unsigned)((m_big + 255) / 256)), dim3(256), 0, ctx->stream>>>(bk[rbig], bv[rbig], bpos, m_big, akeys[0], cur.idx);
+                        seg_writeback_kernel<<<dim3((unsigned)((m_big + 255) / 256)), dim3(256), 0, ctx->stream>>>(bk[rbig], bv[rbig], bpos, m_big, cur.head, rb,
+                                                                                                                 akeys[0], cur.idx);
                         HIPC(hipGetLastError());
                     }
                     AK = akeys[0];
