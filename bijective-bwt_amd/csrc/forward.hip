@@ -704,6 +704,16 @@ __device__ __forceinline__ u64 tied_find(const u32 *__restrict__ tpos, u64 a0, u
     return (lo < a0 && tpos[lo] == q) ? lo : ~0ull;
 }
 
+// cyclic successor inside the factor [s, s + L): position of the h-th symbol after p.  h < L is the common case (one factor
+// holds most of a natural text), and then no division is needed: (p - s) + h < 2 L.
+__device__ __forceinline__ u64 cyclic_successor(u64 p, u64 s, u64 L, u64 h)
+{
+    const u64 hm = h < L ? h : h % L;
+    u64 off = (p - s) + hm;
+    if (off >= L) off -= L;
+    return s + off;
+}
+
 // Rank of a key in the sorted round-0 keys.  A plain binary search over n = 2^30 keys is 30 dependent probes, the last
 // ~14 of them cache misses.  A directory over the keys' top dlog bits (dir[k] = first slot whose key's top bits are >= k,
 // dir[2^dlog] = n) narrows the range to ~n / 2^dlog slots; the keys are close to uniform inside a bucket (entropy-coded
@@ -795,7 +805,7 @@ __global__ __launch_bounds__(256) void keybuild_sparse_kernel(const u32 *__restr
         const u64 f = factor_of(fstart, k, p);
         s = fstart[f]; e = factor_end(fstart, k, n, f);
         const u64 L = e - s;
-        q = s + ((p - s) + h % L) % L;
+        q = cyclic_successor(p, s, L, h);
     } else {
         q = p + h;
         past_end = q >= n;
@@ -847,7 +857,7 @@ __global__ __launch_bounds__(256) void keybuild_h_kernel(const u32 *__restrict__
     if (CYCLIC) {
         const u64 f = factor_of(fstart, k, p);
         const u64 s = fstart[f], L = factor_end(fstart, k, n, f) - s;
-        const u64 q = s + ((p - s) + h % L) % L;
+        const u64 q = cyclic_successor(p, s, L, h);
         r2 = rank[q];
     } else {
         const u64 q = p + h;
