@@ -1194,19 +1194,20 @@ __global__ __launch_bounds__(256) void rank_scatter_pairs_kernel(const u64 *__re
 // The tied list is ordered by group (heads increase along it), so a round's sort by (head, successor rank) only has to
 // order each group by the rank.  On real text most tied elements sit in small groups (53 MiB of source text: 62 % of all
 // element-rounds in groups of <= 8, the late rounds almost entirely pairs), yet a radix sort of the whole list costs 7 passes.
-// seg_small_sort_kernel finds every element's group extent from the list's head array; the first element of a group of at
-// most SEG_CAP sorts it in registers, in place; elements of larger groups are flagged and counted.  If they are the majority
+// seg_small_sort_kernel finds every element's group extent from the list's head array; the members of a group of at most
+// SEG_CAP sort themselves in place (each counts the members ordering before it); elements of larger groups are flagged and counted.  If they are the majority
 // the whole list goes through the radix sort as before; otherwise only they are compacted (scan), radix-sorted
 // and written back to the slots they came from -- the compaction keeps list order, and a sort by (head, rank) keeps groups
 // in list order, so the j-th sorted element belongs to the j-th flagged slot.
 #define SEG_CAP 8
 #define SEG_HALO 8                      // list elements a wave looks at in front of the ones it owns
 #define SEG_OWN  (64 - SEG_HALO - SEG_CAP - 1)      // elements a wave decides: their group's start and end lie inside its 64-lane window
-#define SEG_CE(a, b) do { if (k[a] > k[b]) { const u64 tk = k[a]; k[a] = k[b]; k[b] = tk; const u32 tv = v[a]; v[a] = v[b]; v[b] = tv; } } while (0)
 // A wave looks at 64 consecutive list elements (one coalesced load of their group heads), finds group starts with one
 // __ballot, and decides the SEG_OWN elements in the middle of its window: an element's group start is the highest start
-// bit at or below its lane, the group's end the next start bit above that.  Groups of 2 .. SEG_CAP are sorted in place by
-// their first element; elements of larger groups get big[i] = 1 and are counted (one atomic per wave).
+// bit at or below its lane, the group's end the next start bit above that.  Elements of groups larger than SEG_CAP get
+// big[i] = 1 and are counted (one atomic per wave, spread over 256 counters).  A group of 2 .. SEG_CAP whose first element
+// the wave owns is sorted by its own lanes: each loads its (key, value), counts with SEG_CAP shuffles how many members order
+// before it (ties by list order: stable), and stores itself to that slot of the group -- coalesced loads, near-coalesced stores.
 __global__ __launch_bounds__(256) void seg_small_sort_kernel(const u32 *__restrict__ head, u64 *__restrict__ K, u32 *__restrict__ V, u64 a,
                                                              u8 *__restrict__ big, u64 *__restrict__ big_count)
 {
@@ -1223,49 +1224,37 @@ __global__ __launch_bounds__(256) void seg_small_sort_kernel(const u32 *__restri
     // starts so that a group never extends over them
     const bool start = !inside || e == 0 || h != hp;
     const u64 starts = __ballot(start);
-    const bool owned = inside && lane >= SEG_HALO && lane < SEG_HALO + SEG_OWN;
-    bool is_big = false;
+    // every lane: where does my group start and end inside the window?  (-1 / size 0 = cannot tell from here)
+    const u64 below = lane == 63 ? starts : starts & ((2ull << lane) - 1ull);
+    const int s_lane = below ? 63 - __clzll((long long)below) : -1;
     u32 sz = 0;
-    int s_lane = 0;
-    if (owned) {
-        const u64 below = lane == 63 ? starts : starts & ((2ull << lane) - 1ull);
-        s_lane = below ? 63 - __clzll((long long)below) : -1;
-        if (s_lane < 0 || lane - s_lane >= SEG_CAP) is_big = true;              // start further back than SEG_CAP - 1 elements
-        else {
-            const u64 above = s_lane == 63 ? 0ull : starts >> (s_lane + 1);
-            const int e_lane = above ? s_lane + 1 + (__ffsll((unsigned long long)above) - 1) : 64;
-            sz = (u32)(e_lane - s_lane);
-            if (sz > SEG_CAP) is_big = true;
-        }
-        big[e] = is_big ? 1 : 0;
+    bool too_big = s_lane < 0 || lane - s_lane >= SEG_CAP;         // start further back than SEG_CAP - 1 elements
+    if (!too_big) {
+        const u64 above = s_lane == 63 ? 0ull : starts >> (s_lane + 1);
+        const int e_lane = above ? s_lane + 1 + (__ffsll((unsigned long long)above) - 1) : 64;
+        sz = (u32)(e_lane - s_lane);
+        if (sz > SEG_CAP) too_big = true;
     }
-    const u64 bm = __ballot(owned && is_big);
+    const bool owned = inside && lane >= SEG_HALO && lane < SEG_HALO + SEG_OWN;
+    if (owned) big[e] = too_big ? 1 : 0;
+    const u64 bm = __ballot(owned && too_big);
     if (bm && lane == 0) atomicAdd((unsigned long long *)&big_count[wave & 255], (unsigned long long)__popcll(bm));
-    if (!owned || is_big || s_lane != lane || sz < 2) return;                   // the group's first element sorts it
-    const u64 i = (u64)e;
-    if (sz == 2) {
-        const u64 k0 = K[i], k1 = K[i + 1];
-        if (k0 > k1) { const u32 v0 = V[i], v1 = V[i + 1]; K[i] = k1; K[i + 1] = k0; V[i] = v1; V[i + 1] = v0; }
-        return;
-    }
-    u64 k[SEG_CAP];
-    u32 v[SEG_CAP];
+    // members of a small group whose first element this wave owns sort themselves
+    const bool member = inside && !too_big && sz >= 2 && s_lane >= SEG_HALO && s_lane < SEG_HALO + SEG_OWN;
+    if (__ballot(member) == 0) return;
+    u64 k = 0;
+    u32 v = 0;
+    if (member) { k = K[e]; v = V[e]; }
+    const u32 o = member ? (u32)(lane - s_lane) : 0u;
+    u32 rank = 0;
 #pragma unroll
     for (int j = 0; j < SEG_CAP; j++) {
-        if ((u32)j < sz) { k[j] = K[i + j]; v[j] = V[i + j]; } else { k[j] = ~0ull; v[j] = 0; }      // padding sorts to the end
+        const int src = (s_lane < 0 ? 0 : s_lane) + j;
+        const u64 ko = shfl_t(k, src & 63);
+        if (member && (u32)j < sz && (ko < k || (ko == k && (u32)j < o))) rank++;
     }
-    // Batcher's odd-even merge sort for 8 (19 compare-exchanges)
-    SEG_CE(0, 1); SEG_CE(2, 3); SEG_CE(4, 5); SEG_CE(6, 7);
-    SEG_CE(0, 2); SEG_CE(1, 3); SEG_CE(4, 6); SEG_CE(5, 7);
-    SEG_CE(1, 2); SEG_CE(5, 6);
-    SEG_CE(0, 4); SEG_CE(1, 5); SEG_CE(2, 6); SEG_CE(3, 7);
-    SEG_CE(2, 4); SEG_CE(3, 5);
-    SEG_CE(1, 2); SEG_CE(3, 4); SEG_CE(5, 6);
-#pragma unroll
-    for (int j = 0; j < SEG_CAP; j++)
-        if ((u32)j < sz) { K[i + j] = k[j]; V[i + j] = v[j]; }
+    if (member) { const u64 dst = (u64)e - o + rank; K[dst] = k; V[dst] = v; }
 }
-#undef SEG_CE
 // compaction of the larger groups' elements.  Scan value: low word = flagged elements, high word = flagged groups (their
 // first elements) before the position.  The compacted key carries the group's ordinal among the flagged groups instead of
 // its head slot -- at most m/(SEG_CAP+1) groups, so the radix sort of the compacted list needs fewer key bits (usually a
