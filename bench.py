@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: BWTS build MB/s (+ inverse MB/s) on synthetic input, bit-exact round trip.
 
-    python bench.py --gpus N --steps K --warmup W [--workload zipf|uniform256|dna] [--log2n L]
+    python bench.py --gpus N --steps K --warmup W [--workload zipf|uniform256|dna|text] [--log2n L]
 
-A "step" is one forward transform of one input that is already resident in HBM.  N > 1 runs
-N independent replicas (one input per GPU, seed 1+rank; RCCL is only the barrier), launched
-by torch.distributed.run.  Rank 0 prints ONE JSON line.
+A "step" is one forward transform of one input that is already resident in HBM.  N > 1 runs N independent
+replicas (one input per GPU, seed 1+rank; RCCL is only the barrier and the max-over-ranks of the times): either
+under an outer `python -m torch.distributed.run ... bench.py --gpus N`, or -- when WORLD_SIZE is not set --
+bench.py starts those N ranks itself as a child process before anything here touches a GPU.
+Rank 0 prints ONE JSON line.  At N = 1 the line also carries: the text workload beside the headline one, the
+host-buffer path (bwts_forward / bwts_inverse on unpinned caller memory) and the CLI wall time (`e2e`), and the
+CPU baseline.
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -18,6 +27,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# A process that never touches the GPU: it starts the CLI programs for the e2e leg (the parent has an open GPU
+# context by then) and times them.  Protocol: one JSON request per line on stdin, one JSON answer per line on stdout.
+_HELPER = r'''
+import json, subprocess, sys, time
+for line in sys.stdin:
+    req = json.loads(line)
+    t0 = time.perf_counter()
+    p = subprocess.run(req["cmd"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=req.get("env"))
+    wall = time.perf_counter() - t0
+    print(json.dumps({"rc": p.returncode, "wall_s": wall, "stderr": p.stderr.decode(errors="replace")[-2000:]}), flush=True)
+'''
 
 
 def cpu_baseline(kind, sample_log2n):
@@ -53,7 +74,7 @@ class _SleepEngine:
 
         def as_dict(self):
             return {"kernels": {}, "factors": 0, "rounds": 0, "lyndon_rounds": 0, "key_symbols": 0, "key_bits": 0,
-                    "active_after_round0": 0, "unvisited": 0, "total_ms": 0.0}
+                    "active_after_round0": 0, "unvisited": 0, "total_ms": 0.0, "round_active": []}
 
     class _B:
         def free(self):
@@ -66,6 +87,9 @@ class _SleepEngine:
         return self._B()
 
     def generate(self, *a):
+        pass
+
+    def set_timing(self, level):
         pass
 
     def forward_device(self, *a):
@@ -83,26 +107,166 @@ class _SleepEngine:
         pass
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _accumulate(agg, tm):
+    for name, st in tm.as_dict()["kernels"].items():
+        a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "alg_bytes": 0, "elems": 0})
+        for k in a:
+            a[k] += st[k]
+
+
+def _per_kernel(a):
+    out = {}
+    for name, st in a.items():
+        if st["launches"] and st["ms"] > 0:
+            out[name] = {"ms_per_launch": round(st["ms"] / st["launches"], 4), "launches": st["launches"],
+                         "alg_GBps": round(st["alg_bytes"] / 1e9 / (st["ms"] / 1e3), 1)}
+    return out
+
+
+def _pmc_traffic(kernel_label, per_elem, workload, log2n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/).  The record
+    names the kernel, its bytes per element and the sha256 of the source file it was collected on: a kernel that has
+    changed since reports null instead of a stale figure."""
+    try:
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if not (name.endswith(".json") and "pmc_traffic" in name):
+                continue
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if not str(pm.get("workload", "zipf")).startswith(workload) or pm.get("log2n", 30) != log2n:
+                continue
+            if pm.get("kernel", "").split("<")[0] != kernel_label.split("<")[0] or pm.get("alg_bytes_per_element") != per_elem:
+                continue
+            src = pm.get("source_sha256")
+            if src:
+                cur = hashlib.sha256(open(os.path.join(ROOT, "bijective-bwt_amd", "csrc", "radix.hip"), "rb").read()).hexdigest()
+                if cur != src:
+                    continue
+            return pm["hbm_bytes_per_launch"], name
+    except Exception:
+        pass
+    return None, None
+
+
+def _e2e(ctx, helper, d_in, d_out, n, workload):
+    """The path the CLIs take: caller-owned, unpinned host buffers (bwts_forward / bwts_inverse), and the mk_bwts / unbwts
+    programs on files in tmpfs, started by the helper process."""
+    import numpy as np
+    res = {}
+    x = d_in.download()
+    ymem = d_out.download()                     # forward output of the timed steps (device path)
+
+    def timed(fn, src, reps=3):
+        best, tot = None, 0.0
+        for _ in range(reps):
+            out = np.empty(n, dtype=np.uint8)   # fresh, never-touched output: the first-touch faults are the caller's reality
+            t0 = time.perf_counter()
+            fn(src, out)
+            dt = time.perf_counter() - t0
+            tot += dt
+            best = dt if best is None or dt < best else best
+        return out, tot / reps, best
+
+    ctx.forward_into(x, np.empty(n, dtype=np.uint8))        # warm: staging ring, copy workers, device in/out buffers
+    y, mean_s, best_s = timed(ctx.forward_into, x)
+    tm = ctx.timings()
+    res["host_forward_MBps"] = round(n / 1e6 / mean_s, 1)
+    res["host_forward_best_MBps"] = round(n / 1e6 / best_s, 1)
+    res["host_forward_ms"] = {"wall": round(1e3 * mean_s, 2), "h2d": round(tm.h2d_ms, 2), "device": round(tm.total_ms, 2),
+                              "d2h": round(tm.d2h_ms, 2)}
+    res["host_forward_equals_device_path"] = bool(np.array_equal(y, ymem))
+    back, mean_s, best_s = timed(ctx.inverse_into, y)
+    tm = ctx.timings()
+    res["host_inverse_MBps"] = round(n / 1e6 / mean_s, 1)
+    res["host_inverse_ms"] = {"wall": round(1e3 * mean_s, 2), "h2d": round(tm.h2d_ms, 2), "device": round(tm.total_ms, 2),
+                              "d2h": round(tm.d2h_ms, 2)}
+    res["host_roundtrip_exact"] = bool(np.array_equal(back, x))
+    res["host_buffers"] = "numpy arrays (malloc, unpinned); output allocated fresh for every call"
+    del back
+
+    if helper is not None:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        td = tempfile.mkdtemp(prefix="bwts_bench_", dir=base)
+        try:
+            src, out, rt = os.path.join(td, "in.bin"), os.path.join(td, "out.bwts"), os.path.join(td, "back.bin")
+            x.tofile(src)
+            env = dict(os.environ, BWTS_TIMINGS="1")
+
+            def ask(cmd):
+                helper.stdin.write(json.dumps({"cmd": cmd, "env": env}) + "\n")
+                helper.stdin.flush()
+                return json.loads(helper.stdout.readline())
+
+            pkg_dir = os.path.join(ROOT, "bijective-bwt_amd")
+            a = ask([os.path.join(pkg_dir, "mk_bwts"), src, out])
+            b = ask([os.path.join(pkg_dir, "unbwts"), out, rt])
+            ok = a["rc"] == 0 and b["rc"] == 0
+            res["cli_wall_MBps"] = round(n / 1e6 / a["wall_s"], 1) if a["rc"] == 0 else None
+            res["cli_inverse_wall_MBps"] = round(n / 1e6 / b["wall_s"], 1) if b["rc"] == 0 else None
+            res["cli_wall_s"] = {"mk_bwts": round(a["wall_s"], 3), "unbwts": round(b["wall_s"], 3)}
+            res["cli_phases"] = [l for l in a["stderr"].splitlines() if " time " in l][-6:]
+            if ok:
+                res["cli_output_equals_device_path"] = bool(np.array_equal(np.fromfile(out, dtype=np.uint8), ymem))
+                res["cli_roundtrip_exact"] = bool(np.array_equal(np.fromfile(rt, dtype=np.uint8), x))
+            else:
+                res["cli_error"] = (a["stderr"] + b["stderr"])[-500:]
+            res["cli_files"] = "tmpfs (%s); wall time of the whole process: HIP start-up, context, mmap, transform, write" % (base or td)
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    return res
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="zipf", choices=["zipf", "uniform256", "dna"])
+    ap.add_argument("--workload", default="zipf", choices=["zipf", "uniform256", "dna", "text"])
     ap.add_argument("--log2n", type=int, default=30)
     ap.add_argument("--inverse-steps", type=int, default=2)
+    ap.add_argument("--breakdown-steps", type=int, default=2, help="extra, untimed-for-the-headline steps with every kernel class timed")
     ap.add_argument("--cpu-sample-log2n", type=int, default=26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer / CLI leg")
+    ap.add_argument("--no-text", action="store_true", help="skip the text workload reported beside the headline one")
     ap.add_argument("--selftest-sleep-ms", type=float, default=0.0,
                     help="harness self-test (tests/test_dist_cpu.py): no GPU, no transform; every step sleeps "
                          "(rank+1) x this many ms so the rank/barrier/max-reduce/aggregate logic runs under gloo")
     args = ap.parse_args(argv)
+    raw_args = list(sys.argv[1:] if argv is None else argv)
 
-    import torch
+    # ---- N > 1 without an outer launcher: start the N ranks as a child, before anything here touches a GPU ----------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + raw_args
+        env = dict(os.environ)
+        env.setdefault("OMP_NUM_THREADS", "1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        rc = subprocess.call(cmd, env=env)          # the ranks inherit stdout: rank 0's JSON line is this process's line
+        sys.exit(rc)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     selftest = args.selftest_sleep_ms > 0
+    n_gpus = world
+
+    helper = None
+    if n_gpus == 1 and not selftest and not args.no_e2e:
+        helper = subprocess.Popen([sys.executable, "-c", _HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+
+    import torch
     dev = "cpu" if selftest else "cuda"
     dist = None
     if world > 1:
@@ -112,9 +276,6 @@ def main(argv=None):
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
 
     def barrier():
         if dist is not None:
@@ -132,63 +293,64 @@ def main(argv=None):
     d_in = ctx.alloc(n)
     d_out = ctx.alloc(n)
     d_back = ctx.alloc(n)
-    ctx.generate(args.workload, 1 + rank, n, d_in)
 
-    for _ in range(args.warmup):
-        ctx.forward_device(d_in, n, d_out)
+    def measure(workload, steps, warmup, inverse_steps, breakdown_steps):
+        """K timed forward steps (HIP events only on the dominant kernel), the inverse + round trip, then the breakdown."""
+        ctx.generate(workload, 1 + rank, n, d_in)
+        ctx.set_timing(1)
+        for _ in range(warmup):
+            ctx.forward_device(d_in, n, d_out)
+        main_agg = {}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.forward_device(d_in, n, d_out)          # synchronous: returns when d_out is complete
+            tm = ctx.timings()                          # HIP-event time of the dominant kernel, on the engine's stream
+            _accumulate(main_agg, tm)
+        barrier()
+        fwd_s = time.perf_counter() - t0
+        fwd_info = tm.as_dict()
 
-    # ---- timed region: exactly K forward steps ------------------------------------------
-    agg = {}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.forward_device(d_in, n, d_out)          # synchronous: returns when d_out is complete
-        tm = ctx.timings()                          # HIP-event times recorded on the engine's stream
-        for name, st in tm.as_dict()["kernels"].items():
-            a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "alg_bytes": 0, "elems": 0})
-            for k in a:
-                a[k] += st[k]
-    barrier()
-    fwd_s = time.perf_counter() - t0
-    fwd_info = tm.as_dict()
+        ctx.inverse_device(d_out, n, d_back)            # warm
+        roundtrip = ctx.device_equal(d_in, d_back, n)
+        inv_main = {}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(inverse_steps):
+            ctx.inverse_device(d_out, n, d_back)
+            ti = ctx.timings()
+            _accumulate(inv_main, ti)
+        barrier()
+        inv_s = time.perf_counter() - t0
+        inv_info = ti.as_dict()
 
-    # ---- inverse (reported beside the headline) + bit-exact round trip -----------------------
-    ctx.inverse_device(d_out, n, d_back)            # warm
-    roundtrip = ctx.device_equal(d_in, d_back, n)
-    inv_agg = {}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.inverse_steps):
-        ctx.inverse_device(d_out, n, d_back)
-        ti = ctx.timings()
-        for name, st in ti.as_dict()["kernels"].items():
-            a = inv_agg.setdefault(name, {"ms": 0.0, "launches": 0, "alg_bytes": 0, "elems": 0})
-            for k in a:
-                a[k] += st[k]
-    barrier()
-    inv_s = time.perf_counter() - t0
-    inv_info = ti.as_dict()
+        # every kernel class timed: its own pass, outside the two timed regions
+        agg, inv_agg = {}, {}
+        ctx.set_timing(2)
+        for _ in range(breakdown_steps):
+            ctx.forward_device(d_in, n, d_out)
+            _accumulate(agg, ctx.timings())
+            ctx.inverse_device(d_out, n, d_back)
+            _accumulate(inv_agg, ctx.timings())
+        ctx.set_timing(0)
+        return {"fwd_s": fwd_s, "inv_s": inv_s, "roundtrip": roundtrip, "fwd_info": fwd_info, "inv_info": inv_info,
+                "main": main_agg, "inv_main": inv_main, "agg": agg, "inv_agg": inv_agg}
 
-    times = torch.tensor([fwd_s, inv_s, 0.0 if roundtrip else 1.0], dtype=torch.float64, device=dev)
+    m = measure(args.workload, args.steps, args.warmup, args.inverse_steps, args.breakdown_steps)
+    times = torch.tensor([m["fwd_s"], m["inv_s"], 0.0 if m["roundtrip"] else 1.0], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     fwd_s, inv_s, bad = [float(v) for v in times.tolist()]
 
+    rc = 0
     if rank == 0:
         ms_per_step = 1e3 * fwd_s / args.steps
         value = n_gpus * n / 1e6 / (fwd_s / args.steps)
         inv_value = n_gpus * n / 1e6 / (inv_s / max(args.inverse_steps, 1))
+        fwd_info, inv_info = m["fwd_info"], m["inv_info"]
 
-        def per_kernel(a):
-            out = {}
-            for name, st in a.items():
-                if st["launches"] and st["ms"] > 0:
-                    out[name] = {"ms_per_launch": round(st["ms"] / st["launches"], 4), "launches": st["launches"],
-                                 "alg_GBps": round(st["alg_bytes"] / 1e9 / (st["ms"] / 1e3), 1)}
-            return out
-
-        # dominant kernel: the n-sized LSD passes of round 0 (one template variant, timed under its own class)
-        sc = agg.get("radix_scatter_main") or agg.get("radix_scatter", {"ms": 0.0, "launches": 0, "alg_bytes": 0})
+        # dominant kernel: the n-sized LSD passes of round 0 (one template variant, timed under its own class in the timed region)
+        sc = m["main"].get("radix_scatter_main") or {"ms": 0.0, "launches": 0, "alg_bytes": 0}
         achieved = sc["alg_bytes"] / 1e9 / (sc["ms"] / 1e3) if sc["ms"] > 0 else 0.0
         # which variant that was follows from its algorithmic bytes per element (20/18: packed streams, 26: wide pairs)
         per_elem = sc["alg_bytes"] // max(sc["launches"], 1) // max(n, 1) if sc["launches"] else 0
@@ -196,17 +358,11 @@ def main(argv=None):
             20: "radix_scatter_packed_kernel<false,false,true> (8-bit LSD pass over packed streams: key-low 4 B + value 4 B + key-high|carried byte 2 B)",
             18: "radix_scatter_packed_kernel<false,false,false> (8-bit LSD pass over packed streams: key 4 B + value 4 B + carried byte 1 B)",
         }.get(per_elem, "radix_scatter2_kernel<512,16,4,true,false> (8-bit LSD pass, key 8 B + value 4 B + carried byte)")
-        traffic = None
-        try:    # PMC bytes per launch, collected with rocprofv3 --pmc on this workload (profiles/), only valid for 2^30
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_radix_scatter.json")))
-            if args.log2n == 30 and args.workload == "zipf" and pm.get("kernel", "").split("<")[0] == kernel_label.split("<")[0] \
-                    and pm.get("alg_bytes_per_element") == per_elem:
-                traffic = pm["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+        traffic, traffic_src = _pmc_traffic(kernel_label, per_elem, args.workload, args.log2n)
+        size_label = "%d GiB" % (n >> 30) if n >= 1 << 30 and n % (1 << 30) == 0 else "%d MiB" % (n >> 20) if n >= 1 << 20 else "%d B" % n
         line = {
-            "metric": "BWTS build MB/s on 1 GiB input (+ inverse MB/s); bit-exact round-trip",
-            "value": round(value, 2), "unit": "MB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "metric": "BWTS build MB/s on %s input (+ inverse MB/s); bit-exact round-trip" % size_label,
+            "value": round(value, 2) if bad == 0.0 else None, "unit": "MB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s(n=2^%d, seed=1+rank) resident in HBM, forward BWTS per step" % (args.workload, args.log2n),
@@ -215,26 +371,57 @@ def main(argv=None):
             "roundtrip_exact": bad == 0.0,
             "roofline": {"bound": "hbm", "kernel": kernel_label,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": sc["alg_bytes"] // max(sc["launches"], 1),
-                         "ms_per_launch": round(sc["ms"] / max(sc["launches"], 1), 4), "launches": sc["launches"]},
+                         "ms_per_launch": round(sc["ms"] / max(sc["launches"], 1), 4), "launches": sc["launches"],
+                         "timed": "HIP events on the engine's stream inside the timed region (this class only; the per-class "
+                                  "breakdown under forward.kernels comes from %d separate steps)" % args.breakdown_steps},
             "forward": {"factors": fwd_info["factors"], "rounds": fwd_info["rounds"], "lyndon_rounds": fwd_info["lyndon_rounds"],
                         "key_symbols": fwd_info["key_symbols"], "key_bits": fwd_info["key_bits"],
-                        "active_after_round0": fwd_info["active_after_round0"], "device_ms": round(fwd_info["total_ms"], 3),
-                        "kernels": per_kernel(agg)},
+                        "active_after_round0": fwd_info["active_after_round0"], "round_active": fwd_info.get("round_active"),
+                        "device_ms": round(fwd_info["total_ms"], 3), "kernels": _per_kernel(m["agg"])},
             "inverse": {"cycles": inv_info["factors"], "unvisited": inv_info["unvisited"], "device_ms": round(inv_info["total_ms"], 3),
-                        "kernels": per_kernel(inv_agg)},
+                        "walk_ms_timed_region": round(m["inv_main"].get("walk", {}).get("ms", 0.0) / max(args.inverse_steps, 1), 3),
+                        "kernels": _per_kernel(m["inv_agg"])},
         }
         if selftest:
             line["data"] = "selftest (no transform executed)"
-        if n_gpus == 1 and not args.no_cpu_baseline and not selftest:
-            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_log2n)
-        print(json.dumps(line))
+        if n_gpus == 1 and not selftest:
+            if not args.no_e2e:
+                try:
+                    line["e2e"] = _e2e(ctx, helper, d_in, d_out, n, args.workload)
+                except Exception as e:       # the headline stands on its own; a failure here is reported, not hidden
+                    line["e2e"] = {"error": repr(e)}
+            if not args.no_text and args.workload != "text":
+                # the repeat-rich text workload beside the headline one, same size
+                t = measure("text", 2, 1, 1, 1)
+                ti = t["fwd_info"]
+                line["text"] = {
+                    "workload": "text(n=2^%d, seed=1): zipf stream with back-references of 16 B .. 64 KiB" % args.log2n,
+                    "forward_MBps": round(n / 1e6 / (t["fwd_s"] / 2), 1), "forward_ms": round(1e3 * t["fwd_s"] / 2, 2),
+                    "inverse_MBps": round(n / 1e6 / t["inv_s"], 1), "inverse_ms": round(1e3 * t["inv_s"], 2),
+                    "roundtrip_exact": bool(t["roundtrip"]), "rounds": ti["rounds"], "key_bits": ti["key_bits"], "factors": ti["factors"],
+                    "round_active": ti.get("round_active"), "kernels": _per_kernel(t["agg"]),
+                }
+                if not t["roundtrip"]:
+                    bad = 1.0
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_log2n)
+        print(json.dumps(line), flush=True)
+        if bad != 0.0:
+            print("bench.py: round trip NOT exact", file=sys.stderr)
+            rc = 1
     for b in (d_in, d_out, d_back):
         b.free()
     ctx.close()
+    if helper is not None:
+        helper.stdin.close()
+        helper.wait(timeout=30)
     if dist is not None:
         dist.destroy_process_group()
+    if bad != 0.0:
+        rc = 1
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

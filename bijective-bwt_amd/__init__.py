@@ -21,16 +21,21 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libbwts_hip.so")
 
-KINDS = {"uniform256": 0, "zipf": 1, "dna": 2}
+KINDS = {"uniform256": 0, "zipf": 1, "dna": 2, "text": 3}
 
 K_NAMES = ["histogram", "keybuild", "radix_hist", "radix_scan", "radix_scatter", "rerank", "lyndon", "emit",
            "lf_build", "walk", "listrank", "walk_emit", "other", "radix_scatter_main"]
 K_COUNT = len(K_NAMES)
+MAX_ROUND_STATS = 40
 
-# every symbol include/bwts.h declares
+# every symbol include/bwts.h declares (the drop-in surface) ...
 EXPORTS = [
-    "bwts_ctx_create", "bwts_ctx_destroy", "bwts_forward", "bwts_inverse", "bwts_forward_device",
-    "bwts_inverse_device", "bwts_last_timings", "bwts_kernel_class_name", "bwts_strerror", "bwts_last_hip_error",
+    "bwts_ctx_create", "bwts_ctx_destroy", "bwts_forward", "bwts_inverse", "bwts_forward_sink", "bwts_inverse_sink",
+    "bwts_forward_device", "bwts_inverse_device", "bwts_last_timings", "bwts_kernel_class_name", "bwts_strerror",
+    "bwts_last_hip_error", "bwts_set_timing", "bwts_host_alloc", "bwts_host_free",
+]
+# ... and include/bwts_test.h (harness and unit-test hooks)
+TEST_EXPORTS = [
     "bwts_generate_device", "bwts_device_alloc", "bwts_device_free", "bwts_copy_to_device", "bwts_copy_to_host",
     "bwts_device_equal", "bwts_debug_sort_pairs", "bwts_debug_suffix_array", "bwts_debug_lyndon",
 ]
@@ -51,14 +56,18 @@ class Timings(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_double), ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
                 ("n", ctypes.c_uint64), ("factors", ctypes.c_uint64), ("rounds", ctypes.c_uint32),
                 ("lyndon_rounds", ctypes.c_uint32), ("key_symbols", ctypes.c_uint32), ("key_bits", ctypes.c_uint32),
-                ("active_after_round0", ctypes.c_uint64), ("unvisited", ctypes.c_uint64), ("k", KernelStat * K_COUNT)]
+                ("active_after_round0", ctypes.c_uint64), ("unvisited", ctypes.c_uint64),
+                ("round_active", ctypes.c_uint64 * MAX_ROUND_STATS), ("k", KernelStat * K_COUNT)]
 
     def as_dict(self):
-        d = {f: getattr(self, f) for f, _ in self._fields_ if f != "k"}
+        d = {f: getattr(self, f) for f, _ in self._fields_ if f not in ("k", "round_active")}
+        d["round_active"] = [int(v) for v in self.round_active[: max(int(self.rounds), 1)]]
         d["kernels"] = {K_NAMES[i]: {"ms": self.k[i].ms, "launches": self.k[i].launches, "elems": self.k[i].elems,
                                      "alg_bytes": self.k[i].alg_bytes} for i in range(K_COUNT) if self.k[i].launches}
         return d
 
+
+SINK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
 
 _lib = None
 
@@ -88,6 +97,11 @@ def lib():
         L.bwts_strerror.argtypes = [i32]
         L.bwts_strerror.restype = ctypes.c_char_p
         L.bwts_last_hip_error.argtypes = [vp]
+        L.bwts_set_timing.argtypes = [vp, i32]
+        L.bwts_host_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
+        L.bwts_host_free.argtypes = [vp, vp]
+        for name in ("bwts_forward_sink", "bwts_inverse_sink"):
+            getattr(L, name).argtypes = [vp, vp, u64, SINK_FN, vp]
         L.bwts_generate_device.argtypes = [vp, i32, u64, u64, vp]
         L.bwts_device_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
         L.bwts_device_free.argtypes = [vp, vp]
@@ -190,6 +204,46 @@ class Context:
 
     def inverse_device(self, d_in, n, d_out):
         self._check(lib().bwts_inverse_device(self._h, _ptr(d_in), int(n), _ptr(d_out)))
+
+    def set_timing(self, level=2):
+        """HIP-event times in timings(): 0 off (default), 1 dominant kernels only, 2 every class (~1 ms per call at 1 GiB)."""
+        self._check(lib().bwts_set_timing(self._h, int(level)))
+
+    def _sink(self, fn, data):
+        a = _u8(data)
+        pieces = []
+
+        def take(_user, ptr, length):
+            pieces.append(ctypes.string_at(ptr, length))
+            return 0
+
+        cb = SINK_FN(take)
+        self._check(fn(self._h, a.ctypes.data, a.size, cb, None))
+        return np.frombuffer(b"".join(pieces), dtype=np.uint8)
+
+    def forward_sink(self, data):
+        """forward() with the output delivered through the sink callback (what the CLIs use)."""
+        return self._sink(lib().bwts_forward_sink, data)
+
+    def inverse_sink(self, data):
+        return self._sink(lib().bwts_inverse_sink, data)
+
+    def host_alloc(self, nbytes):
+        """A pinned host block as a numpy uint8 array (freed with the context or host_free())."""
+        p = ctypes.c_void_p()
+        self._check(lib().bwts_host_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        arr = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(nbytes),))
+        return arr, p.value
+
+    def host_free(self, ptr):
+        self._check(lib().bwts_host_free(self._h, ptr))
+
+    def forward_into(self, a, out):
+        """bwts_forward on caller-provided numpy buffers (no allocation inside the call)."""
+        self._check(lib().bwts_forward(self._h, a.ctypes.data, a.size, out.ctypes.data))
+
+    def inverse_into(self, a, out):
+        self._check(lib().bwts_inverse(self._h, a.ctypes.data, a.size, out.ctypes.data))
 
     def timings(self):
         t = Timings()

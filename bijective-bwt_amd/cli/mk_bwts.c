@@ -7,13 +7,21 @@
  *   no outfile: the raw transform goes to standard output                 (:54)
  *   outfile cannot be opened: message + perror(name), exit 1              (:55-59)
  *   output is exactly the input's length: no header, no index             (:60)
- * The transform itself (reference :47-52) is bwts_forward() from libbwts_hip.so.
- * BWTS_TIMINGS=1 prints the reference's MARK_TIME phase lines (:13-22) on stderr,
- * taken from HIP events.
+ * Built with -DBWTS_AUTONAME this source is mk_bwts_new_algo, the program the reference's `make test` drives
+ * (/root/reference/mk_bwts_new_algo.c:37-65, :192-234): same transform, but without an outfile the output goes to
+ * "<infile>_XXXXXX.bwts" (mkstemps) and "Writing to <name>" is printed on stdout (:210-216).
+ *
+ * The transform itself (reference :47-52) is bwts_forward_sink() from libbwts_hip.so: the output is written piece by
+ * piece as it arrives from the GPU, so no second n-byte buffer exists on the host.
+ * Phase lines of the reference's MARK_TIME (:13-22, :50,:124,:168,:190,:62) go to stderr when built with
+ * -DSHOW_TIMINGS (as in the reference, Makefile:2-3) or run with BWTS_TIMINGS=1; device phases come from HIP events.
  */
+#define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "bwts.h"
 #include "map_file.h"
@@ -24,57 +32,125 @@ static void fail(const char *what, int code)
 	exit(1);
 }
 
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static double write_s;
+
+static int write_piece(void *user, const uint8_t *data, uint64_t len)
+{
+	const double t0 = now_s();
+	const size_t done = fwrite(data, 1, (size_t)len, (FILE *)user);
+	write_s += now_s() - t0;
+	return done == (size_t)len ? 0 : 1;
+}
+
+static FILE *open_output(const char *explicit_name, const char *in_name)
+{
+	FILE *fp;
+
+	if (explicit_name) {
+#ifdef BWTS_AUTONAME
+		fp = fopen(explicit_name, "wb");
+#else
+		fp = fopen(explicit_name, "w");
+#endif
+		if (!fp) {
+			fprintf(stderr, "Couldn't open BWTS file for writing\n");
+			perror(explicit_name);
+			exit(1);
+		}
+		return fp;
+	}
+#ifdef BWTS_AUTONAME
+	{
+		char *name = NULL;
+		int fd;
+
+		if (asprintf(&name, "%s_XXXXXX.bwts", in_name) <= 0) {
+			fprintf(stderr, "Allocating outfile name failed. Abort\n");
+			exit(1);
+		}
+		fd = mkstemps(name, 5);
+		printf("Writing to %s\n", name);
+		fflush(stdout);
+		fp = fd >= 0 ? fdopen(fd, "w") : NULL;
+		if (!fp) {
+			fprintf(stderr, "Couldn't open BWTS file for writing\n");
+			perror(name);
+			exit(1);
+		}
+		free(name);
+		return fp;
+	}
+#else
+	(void)in_name;
+	return stdout;
+#endif
+}
+
 int main(int argc, char **argv)
 {
 	unsigned char *text;
 	long len;
-	unsigned char *bwts;
 	bwts_ctx *ctx;
 	FILE *fp;
 	int rc;
 	const char *dev = getenv("BWTS_DEVICE");
-	const char *show = getenv("BWTS_TIMINGS");
+	const char *show_env = getenv("BWTS_TIMINGS");
+#ifdef SHOW_TIMINGS
+	const int show = 1;
+#else
+	const int show = show_env && show_env[0] == '1';
+#endif
+	double t_start, t_wall;
 
 	if (argc < 2) {
 		fprintf(stderr, "Usage: mk_bwts_sa <infile> [<outfile.bwts>]\n");
+#ifdef BWTS_AUTONAME
+		fprintf(stderr, "If outfile is not supplied, a unique file name is generated\n");
+#else
 		fprintf(stderr, "If unspecified, output is written to standard output\n");
+#endif
 		exit(1);
 	}
 	map_in(text, len, argv[1]);
 
-	bwts = (unsigned char *)malloc((size_t)len);
-	if (!bwts) {
-		perror("malloc");
-		exit(1);
-	}
 	if ((rc = bwts_ctx_create(&ctx, dev ? atoi(dev) : 0)) != BWTS_OK)
 		fail("cannot open GPU context", rc);
-	if ((rc = bwts_forward(ctx, text, (uint64_t)len, bwts)) != BWTS_OK)
-		fail("transform failed", rc);
+	if (show)
+		bwts_set_timing(ctx, 2);
+	fp = open_output(argc < 3 ? NULL : argv[2], argv[1]);
 
-	if (show && show[0] == '1') {
+	t_start = now_s();
+	if ((rc = bwts_forward_sink(ctx, text, (uint64_t)len, write_piece, fp)) != BWTS_OK)
+		fail("transform failed", rc);
+	if (fp != stdout)
+		fclose(fp);
+	else
+		fflush(fp);
+	t_wall = now_s() - t_start;
+
+	if (show) {
 		bwts_timings t;
 		bwts_last_timings(ctx, &t);
-		/* same labels as MARK_TIME (mk_bwts_sa.c:50,124,168,190); seconds of device time */
+		/* the reference's five labels (mk_bwts_sa.c:50,124,168,190,62); seconds.  The engine has no separate ISA or
+		 * fix-up pass: "Compute ISA" is the regrouping / rank work of the doubling sort, "Fix sort order" the factor
+		 * search (cyclic ranking needs no fix-up), "Write BWTS" the copy out of the GPU overlapped with fwrite. */
 		fprintf(stderr, "Suffix sort time %0.3f\n",
 			1e-3 * (t.k[BWTS_K_KEYBUILD].ms + t.k[BWTS_K_RADIX_HIST].ms + t.k[BWTS_K_RADIX_SCAN].ms +
 				t.k[BWTS_K_RADIX_SCATTER].ms + t.k[BWTS_K_HISTOGRAM].ms));
 		fprintf(stderr, "Compute ISA time %0.3f\n", 1e-3 * t.k[BWTS_K_RERANK].ms);
 		fprintf(stderr, "Fix sort order time %0.3f\n", 1e-3 * t.k[BWTS_K_LYNDON].ms);
 		fprintf(stderr, "Generate BWTS time %0.3f\n", 1e-3 * (t.k[BWTS_K_EMIT].ms + t.k[BWTS_K_OTHER].ms));
-		fprintf(stderr, "Transform (device) time %0.3f  H2D %0.3f  D2H %0.3f\n", 1e-3 * t.total_ms, 1e-3 * t.h2d_ms,
-			1e-3 * t.d2h_ms);
+		fprintf(stderr, "Write BWTS time %0.3f\n", 1e-3 * t.d2h_ms);
+		fprintf(stderr, "Transform (device) time %0.3f  H2D %0.3f  D2H+write %0.3f (fwrite %0.3f)  wall %0.3f\n", 1e-3 * t.total_ms,
+			1e-3 * t.h2d_ms, 1e-3 * t.d2h_ms, write_s, t_wall);
 	}
 	bwts_ctx_destroy(ctx);
-
-	fp = argc < 3 ? stdout : fopen(argv[2], "w");
-	if (!fp) {
-		fprintf(stderr, "Couldn't open BWTS file for writing\n");
-		perror(argv[2]);
-		exit(1);
-	}
-	fwrite(bwts, 1, (size_t)len, fp);
-	if (fp != stdout)
-		fclose(fp);
 	return 0;
 }

@@ -7,7 +7,8 @@
  *   outfile given: opened "wb"; failure prints a message + perror(name), exit 1  (:141-149)
  *   no outfile: "<infile>_XXXXXX" is created with mkstemps and
  *               "Writing to <name>" is printed on stdout                         (:152-158)
- * The transform itself (reference :31-86) is bwts_inverse() from libbwts_hip.so.
+ * The transform itself (reference :31-86) is bwts_inverse_sink() from libbwts_hip.so; the text is written piece by
+ * piece as it arrives from the GPU (reference: one fwrite of the whole buffer, :173).
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -41,6 +42,7 @@ static FILE *open_output(const char *explicit_name, const char *in_name)
 		}
 		fd = mkstemps(name, 0);
 		printf("Writing to %s\n", name);
+		fflush(stdout);
 		fp = fd >= 0 ? fdopen(fd, "w") : NULL;
 		if (!fp) {
 			fprintf(stderr, "Couldn't open output file for writing\n");
@@ -52,15 +54,20 @@ static FILE *open_output(const char *explicit_name, const char *in_name)
 	}
 }
 
+static int write_piece(void *user, const uint8_t *data, uint64_t len)
+{
+	return fwrite(data, 1, (size_t)len, (FILE *)user) == (size_t)len ? 0 : 1;
+}
+
 int main(int argc, char **argv)
 {
 	unsigned char *bwts;
 	long len;
-	unsigned char *text;
 	bwts_ctx *ctx;
 	FILE *fp;
 	int rc;
 	const char *dev = getenv("BWTS_DEVICE");
+	const char *show = getenv("BWTS_TIMINGS");
 
 	if (argc < 2) {
 		fprintf(stderr, "Usage: unbwts <infile.bwts> [<outfile>]\n");
@@ -69,20 +76,22 @@ int main(int argc, char **argv)
 	}
 	map_in(bwts, len, argv[1]);
 
-	text = (unsigned char *)malloc((size_t)len);
-	if (!text) {
-		perror("malloc");
-		exit(1);
-	}
-	if ((rc = bwts_ctx_create(&ctx, dev ? atoi(dev) : 0)) != BWTS_OK ||
-	    (rc = bwts_inverse(ctx, bwts, (uint64_t)len, text)) != BWTS_OK) {
+	if ((rc = bwts_ctx_create(&ctx, dev ? atoi(dev) : 0)) != BWTS_OK) {
 		fprintf(stderr, "unbwts: %s\n", bwts_strerror(rc));
 		exit(1);
 	}
-	bwts_ctx_destroy(ctx);
-
 	fp = open_output(argc < 3 ? NULL : argv[2], argv[1]);
-	fwrite(text, 1, (size_t)len, fp);
+	if ((rc = bwts_inverse_sink(ctx, bwts, (uint64_t)len, write_piece, fp)) != BWTS_OK) {
+		fprintf(stderr, "unbwts: %s\n", bwts_strerror(rc));
+		exit(1);
+	}
 	fclose(fp);
+	if (show && show[0] == '1') {
+		bwts_timings t;
+		bwts_last_timings(ctx, &t);
+		fprintf(stderr, "Transform (device) time %0.3f  H2D %0.3f  D2H+write %0.3f\n", 1e-3 * t.total_ms, 1e-3 * t.h2d_ms,
+			1e-3 * t.d2h_ms);
+	}
+	bwts_ctx_destroy(ctx);
 	return 0;
 }

@@ -1,5 +1,6 @@
 // api.hip -- the C-ABI of include/bwts.h: context, arenas, staging, timing, test hooks.
 #include "internal.h"
+#include "../../include/bwts_test.h"
 
 #include <new>
 #include <stdio.h>
@@ -50,6 +51,14 @@ int aux_reserve(bwts_ctx *ctx, size_t bytes, char **base)
     return BWTS_OK;
 }
 
+int ensure_dyn_lds(bwts_ctx *ctx, const void *kernel, size_t bytes)
+{
+    for (const void *k : ctx->lds_granted) if (k == kernel) return BWTS_OK;
+    HIPC(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->lds_granted.push_back(kernel);
+    return BWTS_OK;
+}
+
 // ------------------------------------------------------------------------------------
 // timing spans
 // ------------------------------------------------------------------------------------
@@ -75,7 +84,7 @@ int span_begin(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes)
     ctx->tm.k[cls].launches++;
     ctx->tm.k[cls].elems += elems;
     ctx->tm.k[cls].alg_bytes += alg_bytes;
-    if (!ctx->timing) return -1;
+    if (ctx->timing < 2 && !(ctx->timing == 1 && (cls == BWTS_K_RADIX_SCATTER_MAIN || cls == BWTS_K_WALK))) return -1;
     TimedSpan sp;
     sp.cls = cls;
     sp.a = take_event(ctx);
@@ -122,7 +131,7 @@ extern "C" int bwts_ctx_create(bwts_ctx **out, int device_id)
     bwts_ctx *ctx = new (std::nothrow) bwts_ctx();
     if (!ctx) return BWTS_E_NOMEM;
     ctx->device = device_id;
-    ctx->timing = true;
+    { const char *e = getenv("BWTS_TIMINGS"); ctx->timing = (e && e[0] == '1') ? 2 : 0; }
     if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return BWTS_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BWTS_E_HIP; }
     void *p = nullptr;
@@ -147,7 +156,13 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
-    for (int i = 0; i < 2; i++) if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
+    if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
+    for (int i = 0; i < STAGE_SLOTS; i++) {
+        if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
+        if (ctx->slot_ev[i]) (void)hipEventDestroy(ctx->slot_ev[i]);
+    }
+    for (int i = 0; i < 2; i++) if (ctx->d_io[i]) (void)hipFree(ctx->d_io[i]);
+    for (const auto &b : ctx->host_blocks) (void)hipHostFree(b.first);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -161,9 +176,7 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
 {
     if (!ctx || !d_in || !d_out || n == 0) return BWTS_E_ARG;
     HIPC(hipSetDevice(ctx->device));
-    const double keep_h2d = ctx->tm.h2d_ms;
     spans_reset(ctx);
-    ctx->tm.h2d_ms = keep_h2d;
     ctx->tm.n = n;
     HIPC(hipEventRecord(ctx->ev_begin, ctx->stream));
     int rc = fn(ctx, (const u8 *)d_in, n, (u8 *)d_out);
@@ -178,73 +191,164 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
 
 extern "C" int bwts_forward_device(bwts_ctx *ctx, const void *d_in, uint64_t n, void *d_out)
 {
-    if (ctx) ctx->tm.h2d_ms = 0;
     return run_device(ctx, forward_device_impl, d_in, n, d_out);
 }
 
 extern "C" int bwts_inverse_device(bwts_ctx *ctx, const void *d_in, uint64_t n, void *d_out)
 {
-    if (ctx) ctx->tm.h2d_ms = 0;
     return run_device(ctx, inverse_device_impl, d_in, n, d_out);
 }
 
-// Host buffers (typically an mmap of the input file): chunked through two pinned bounce
-// buffers so the page-in of chunk i+1 overlaps the DMA of chunk i.
-#define STAGE_CHUNK ((size_t)64 << 20)
+// ------------------------------------------------------------------------------------
+// host-buffer entry points (the path of the CLIs: mk_bwts_sa.c:41-60, unbwts.c:29-89)
+// ------------------------------------------------------------------------------------
+// Caller memory (typically an mmap of the input file, and a fresh malloc for the output) is not pinned, so it cannot be
+// a DMA target.  It moves through a ring of STAGE_SLOTS pinned buffers: while the DMA engine works on one slot the copy
+// workers fill (or drain) the next, and a slot is reused once ITS event has fired -- nothing waits for the whole stream.
+// Memory from bwts_host_alloc() is pinned already and is transferred in one piece.
+#define STAGE_CHUNK ((size_t)8 << 20)
 
-static int ensure_pinned(bwts_ctx *ctx)
+void CopyPool::part(int i)
 {
-    for (int i = 0; i < 2; i++) {
+    // page-aligned cuts: two workers never fault on the same page of a fresh destination
+    const size_t per = ((len / (size_t)parts) + 4095) & ~(size_t)4095;
+    const size_t lo = per * (size_t)i < len ? per * (size_t)i : len;
+    const size_t hi = i + 1 == parts ? len : (lo + per < len ? lo + per : len);
+    if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
+}
+
+void CopyPool::start(int threads)
+{
+    parts = threads < 1 ? 1 : threads;
+    for (int t = 1; t < parts; t++) {
+        workers.emplace_back([this, t] {
+            u64 seen = 0;
+            for (;;) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_work.wait(lk, [&] { return stop || generation != seen; });
+                    if (stop) return;
+                    seen = generation;
+                }
+                part(t);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (--pending == 0) cv_done.notify_one();
+                }
+            }
+        });
+    }
+}
+
+void CopyPool::copy(void *d, const void *s_, size_t n)
+{
+    if (parts == 1 || n < ((size_t)1 << 20)) { memcpy(d, s_, n); return; }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        dst = (char *)d; src = (const char *)s_; len = n;
+        pending = parts - 1;
+        generation++;
+    }
+    cv_work.notify_all();
+    part(0);
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+}
+
+void CopyPool::shutdown()
+{
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+    }
+    cv_work.notify_all();
+    for (std::thread &t : workers) t.join();
+    workers.clear();
+}
+
+static int ensure_staging(bwts_ctx *ctx)
+{
+    for (int i = 0; i < STAGE_SLOTS; i++) {
         if (!ctx->pinned[i]) {
             void *p = nullptr;
             if (hipHostMalloc(&p, STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
             ctx->pinned[i] = (char *)p;
         }
+        if (!ctx->slot_ev[i]) HIPC(hipEventCreateWithFlags(&ctx->slot_ev[i], hipEventDisableTiming));
     }
     ctx->pinned_cap = STAGE_CHUNK;
+    if (!ctx->pool) {
+        int threads = 6;                                   // BWTS_COPY_THREADS: 1 = the calling thread alone
+        if (const char *e = getenv("BWTS_COPY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) threads = v; }
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && (unsigned)threads > hw) threads = (int)hw;
+        ctx->pool = new (std::nothrow) CopyPool();
+        if (!ctx->pool) return BWTS_E_NOMEM;
+        ctx->pool->start(threads);
+    }
     return BWTS_OK;
+}
+
+static bool is_pinned_block(const bwts_ctx *ctx, const void *p, u64 n)
+{
+    for (const auto &b : ctx->host_blocks)
+        if ((const char *)p >= b.first && (const char *)p + n <= b.first + b.second) return true;
+    return false;
 }
 
 static int staged_h2d(bwts_ctx *ctx, u8 *d_dst, const u8 *h_src, u64 n)
 {
-    BWTS_TRY(ensure_pinned(ctx));
-    hipEvent_t done[2];
-    HIPC(hipEventCreate(&done[0]));
-    HIPC(hipEventCreate(&done[1]));
-    int rc = BWTS_OK;
+    if (is_pinned_block(ctx, h_src, n)) {
+        HIPC(hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+        return BWTS_OK;
+    }
+    BWTS_TRY(ensure_staging(ctx));
     u64 off = 0;
-    for (int i = 0; off < n; i ^= 1) {
+    for (u64 c = 0; off < n; c++) {
+        const int slot = (int)(c % STAGE_SLOTS);
         const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
-        if (off >= 2 * STAGE_CHUNK && hipEventSynchronize(done[i]) != hipSuccess) { rc = BWTS_E_HIP; break; }
-        memcpy(ctx->pinned[i], h_src + off, len);
-        if (hipMemcpyAsync(d_dst + off, ctx->pinned[i], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipEventRecord(done[i], ctx->stream) != hipSuccess) { rc = BWTS_E_HIP; break; }
+        if (c >= STAGE_SLOTS) HIPC(hipEventSynchronize(ctx->slot_ev[slot]));       // the slot's previous DMA has read it
+        ctx->pool->copy(ctx->pinned[slot], h_src + off, len);
+        HIPC(hipMemcpyAsync(d_dst + off, ctx->pinned[slot], len, hipMemcpyHostToDevice, ctx->stream));
+        HIPC(hipEventRecord(ctx->slot_ev[slot], ctx->stream));
         off += len;
     }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BWTS_E_HIP;
-    (void)hipEventDestroy(done[0]);
-    (void)hipEventDestroy(done[1]);
-    return rc;
+    HIPC(hipStreamSynchronize(ctx->stream));
+    return BWTS_OK;
 }
 
-static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n)
+// the result leaves in consecutive pieces: to h_dst (copy workers), or to the caller's sink straight from the staging slot
+static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n, bwts_sink_fn sink, void *user)
 {
-    BWTS_TRY(ensure_pinned(ctx));
-    u64 off = 0;
-    // copy chunk i to pinned[i&1], then memcpy out while the next chunk is in flight
-    size_t prev_len = 0; u64 prev_off = 0; int prev_buf = -1;
-    for (int i = 0; off < n || prev_buf >= 0; i ^= 1) {
-        size_t len = 0;
-        if (off < n) {
-            len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
-            HIPC(hipMemcpyAsync(ctx->pinned[i], d_src + off, len, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        if (prev_buf >= 0) memcpy(h_dst + prev_off, ctx->pinned[prev_buf], prev_len);
+    if (!sink && is_pinned_block(ctx, h_dst, n)) {
+        HIPC(hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
         HIPC(hipStreamSynchronize(ctx->stream));
-        if (off < n) { prev_buf = i; prev_off = off; prev_len = len; off += len; }
-        else prev_buf = -1;
+        return BWTS_OK;
     }
-    return BWTS_OK;
+    BWTS_TRY(ensure_staging(ctx));
+    const u64 chunks = (n + STAGE_CHUNK - 1) / STAGE_CHUNK;
+    auto issue = [&](u64 c) -> int {
+        const u64 off = c * STAGE_CHUNK;
+        const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
+        const int slot = (int)(c % STAGE_SLOTS);
+        HIPC(hipMemcpyAsync(ctx->pinned[slot], d_src + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(hipEventRecord(ctx->slot_ev[slot], ctx->stream));
+        return BWTS_OK;
+    };
+    for (u64 c = 0; c < chunks && c < STAGE_SLOTS; c++) BWTS_TRY(issue(c));
+    int rc = BWTS_OK;
+    for (u64 c = 0; c < chunks; c++) {
+        const u64 off = c * STAGE_CHUNK;
+        const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
+        const int slot = (int)(c % STAGE_SLOTS);
+        if (hipEventSynchronize(ctx->slot_ev[slot]) != hipSuccess) { rc = BWTS_E_HIP; break; }
+        if (sink) { if (sink(user, (const uint8_t *)ctx->pinned[slot], len) != 0) { rc = BWTS_E_SINK; break; } }
+        else ctx->pool->copy(h_dst + off, ctx->pinned[slot], len);
+        if (c + STAGE_SLOTS < chunks && (rc = issue(c + STAGE_SLOTS)) != BWTS_OK) break;
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == BWTS_OK) rc = BWTS_E_HIP;
+    return rc;
 }
 
 static double wall_ms(void)
@@ -254,36 +358,90 @@ static double wall_ms(void)
     return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
 }
 
-static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_t n, uint8_t *out)
+// device-side copies of the caller's input and output stay with the context (grown, never shrunk)
+static int ensure_io(bwts_ctx *ctx, u64 n)
 {
-    if (!ctx || !in || !out || n == 0) return BWTS_E_ARG;
-    HIPC(hipSetDevice(ctx->device));
-    void *d_in = nullptr, *d_out = nullptr;
-    if (hipMalloc(&d_in, n) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
-    if (hipMalloc(&d_out, n) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_in); return BWTS_E_NOMEM; }
-    double t0 = wall_ms();
-    int rc = staged_h2d(ctx, (u8 *)d_in, in, n);
-    const double h2d = wall_ms() - t0;
-    if (rc == BWTS_OK) { ctx->tm.h2d_ms = h2d; rc = run_device(ctx, fn, d_in, n, d_out); }
-    if (rc == BWTS_OK) {
-        t0 = wall_ms();
-        rc = staged_d2h(ctx, out, (const u8 *)d_out, n);
-        ctx->tm.d2h_ms = wall_ms() - t0;
-        ctx->tm.h2d_ms = h2d;
+    for (int i = 0; i < 2; i++) {
+        if (ctx->d_io_cap[i] >= n) continue;
+        if (ctx->d_io[i]) { HIPC(hipFree(ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
+        void *p = nullptr;
+        const size_t cap = align_up((size_t)n, 1 << 20);
+        if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+        ctx->d_io[i] = (u8 *)p;
+        ctx->d_io_cap[i] = cap;
     }
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
+    return BWTS_OK;
+}
+
+static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_t n, uint8_t *out, bwts_sink_fn sink, void *user)
+{
+    if (!ctx || !in || (!out && !sink) || n == 0) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    BWTS_TRY(ensure_io(ctx, n));
+    double t0 = wall_ms();
+    BWTS_TRY(staged_h2d(ctx, ctx->d_io[0], in, n));
+    const double h2d = wall_ms() - t0;
+    BWTS_TRY(run_device(ctx, fn, ctx->d_io[0], n, ctx->d_io[1]));
+    t0 = wall_ms();
+    const int rc = staged_d2h(ctx, out, ctx->d_io[1], n, sink, user);
+    ctx->tm.d2h_ms = wall_ms() - t0;
+    ctx->tm.h2d_ms = h2d;
     return rc;
 }
 
 extern "C" int bwts_forward(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out)
 {
-    return run_host(ctx, forward_device_impl, in, n, out);
+    return run_host(ctx, forward_device_impl, in, n, out, nullptr, nullptr);
 }
 
 extern "C" int bwts_inverse(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out)
 {
-    return run_host(ctx, inverse_device_impl, in, n, out);
+    return run_host(ctx, inverse_device_impl, in, n, out, nullptr, nullptr);
+}
+
+extern "C" int bwts_forward_sink(bwts_ctx *ctx, const uint8_t *in, uint64_t n, bwts_sink_fn sink, void *user)
+{
+    if (!sink) return BWTS_E_ARG;
+    return run_host(ctx, forward_device_impl, in, n, nullptr, sink, user);
+}
+
+extern "C" int bwts_inverse_sink(bwts_ctx *ctx, const uint8_t *in, uint64_t n, bwts_sink_fn sink, void *user)
+{
+    if (!sink) return BWTS_E_ARG;
+    return run_host(ctx, inverse_device_impl, in, n, nullptr, sink, user);
+}
+
+extern "C" int bwts_host_alloc(bwts_ctx *ctx, uint64_t bytes, void **h_ptr)
+{
+    if (!ctx || !h_ptr) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+    ctx->host_blocks.emplace_back((char *)p, (size_t)bytes);
+    *h_ptr = p;
+    return BWTS_OK;
+}
+
+extern "C" int bwts_host_free(bwts_ctx *ctx, void *h_ptr)
+{
+    if (!ctx) return BWTS_E_ARG;
+    if (!h_ptr) return BWTS_OK;
+    for (size_t i = 0; i < ctx->host_blocks.size(); i++) {
+        if (ctx->host_blocks[i].first == (char *)h_ptr) {
+            ctx->host_blocks.erase(ctx->host_blocks.begin() + (long)i);
+            HIPC(hipSetDevice(ctx->device));
+            HIPC(hipHostFree(h_ptr));
+            return BWTS_OK;
+        }
+    }
+    return BWTS_E_ARG;
+}
+
+extern "C" int bwts_set_timing(bwts_ctx *ctx, int level)
+{
+    if (!ctx || level < 0 || level > 2) return BWTS_E_ARG;
+    ctx->timing = level;
+    return BWTS_OK;
 }
 
 // ------------------------------------------------------------------------------------
@@ -313,6 +471,7 @@ extern "C" const char *bwts_strerror(int code)
     case BWTS_E_HIP: return "HIP runtime error";
     case BWTS_E_RANGE: return "input length beyond the engine's index range";
     case BWTS_E_INTERNAL: return "internal invariant violated";
+    case BWTS_E_SINK: return "the caller's output sink reported an error";
     default: return "unknown error";
     }
 }
@@ -398,7 +557,8 @@ static int upload_text(bwts_ctx *ctx, const uint8_t *in, uint64_t n, u8 **d_T)
 {
     void *p = nullptr;
     if (hipMalloc(&p, n) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
-    if (hipMemcpy(p, in, n, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); return BWTS_E_HIP; }
+    if (hipMemcpyAsync(p, in, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipFree(p); return BWTS_E_HIP; }
     *d_T = (u8 *)p;
     return BWTS_OK;
 }
@@ -435,7 +595,9 @@ extern "C" int bwts_debug_lyndon(bwts_ctx *ctx, const uint8_t *in, uint64_t n, u
         u32 *tmp = (u32 *)malloc((size_t)(take ? take : 1) * 4);
         if (!tmp) rc = BWTS_E_NOMEM;
         else {
-            if (hipMemcpy(tmp, fstart, take * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = BWTS_E_HIP;
+            // on the context's stream: it is non-blocking, so the null stream would not wait for the factor list's last copy
+            if (hipMemcpyAsync(tmp, fstart, take * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) rc = BWTS_E_HIP;
             for (u64 i = 0; i < take; i++) h_starts[i] = tmp[i];
             free(tmp);
         }

@@ -1371,6 +1371,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
     u64 a = ctx->h_small[CNT_ACTIVE];
     *active0_out = a;
+    if (CYCLIC) ctx->tm.round_active[0] = a;
     sp.tie_slots = cur.slot;        // stays untouched by the later rounds
     sp.tie_count = a;
     u32 rounds = 1;
@@ -1447,12 +1448,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
                 const u32 nw = (u32)((n + (1ull << wlog) - 1) >> wlog);
                 u32 *win_fill = sp.tile_hist;
                 HIPC(hipMemsetAsync(win_fill, 0, (size_t)nw * RB_FILL_STRIDE * sizeof(u32), ctx->stream));
-                static bool attr_set = false;
-                if (!attr_set) {
-                    HIPC(hipFuncSetAttribute((const void *)rank_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)rank_partition_lds_bytes(RB_MAX_WINDOWS)));
-                    attr_set = true;
-                }
+                BWTS_TRY(ensure_dyn_lds(ctx, (const void *)rank_partition_kernel, rank_partition_lds_bytes(RB_MAX_WINDOWS)));
                 rank_partition_kernel<<<dim3((unsigned)((n + RB_CHUNK - 1) / RB_CHUNK)), dim3(RB_THREADS), rank_partition_lds_bytes(nw), ctx->stream>>>(
                     SA, n, flag_heads, flag_pre, wlog, nw, win_fill, K0);
                 rank_scatter_pairs_kernel<<<dim3(nw * RB_BLOCKS_PER_WINDOW), dim3(256), 0, ctx->stream>>>(K0, win_fill, wlog, sp.rank);
@@ -1563,6 +1559,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             cur = sets[nxt];
             nxt ^= 1;
             a = a_new;
+            if (CYCLIC && rounds - 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[rounds - 1] = a;
             if (a == 0) break;
             if (CYCLIC && splits == 0) break;               // partition stable under doubling: equal infinite words
             if (!CYCLIC && h >= n) return BWTS_E_INTERNAL;  // suffixes are distinct; cannot happen

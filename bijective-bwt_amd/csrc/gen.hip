@@ -18,6 +18,29 @@ __constant__ u8 c_zipf_alpha[96] = {
     'E', 'T', 'A', 'O', 'I', 'N', 'S', 'H', 'R', 'D', 'L', 'C', 'U', 'M', 'W', 'F', 'G', 'Y', 'P', 'B', 'V', 'K', 'J', 'X', 'Q', 'Z',
     '!', '$', '%', '*', '+', '?', '@', '\\', '^', '`', '{', '}', '~'};
 
+// kind 3 ("text"): the zipf stream with back-references; a position is redirected through the largest copy window that
+// holds it until it lies in none.  Same integer definition as the CPU generator the tests compare against.
+#define TEXT_LEVEL_SALT 0xD1B54A32D192ED03ull
+__device__ __forceinline__ u64 text_resolve(u64 seed, u64 p)
+{
+    int l = 16;
+    while (l >= 4) {
+        const u64 w = p >> l;
+        if (w) {
+            const u64 h = splitmix_at(seed + (u64)l * TEXT_LEVEL_SALT, w);
+            const u64 mask = l < 8 ? 7u : l < 12 ? 15u : 31u;
+            if ((h & mask) == 0) {
+                const u64 span = ((w - 1) << l) + 1;
+                p = (h >> 8) % span + (p & ((1ull << l) - 1ull));
+                l = 16;
+                continue;
+            }
+        }
+        l--;
+    }
+    return p;
+}
+
 // each thread produces 8 consecutive bytes
 __global__ __launch_bounds__(256) void generate_kernel(int kind, u64 seed, u64 n, u8 *__restrict__ out)
 {
@@ -45,7 +68,7 @@ __global__ __launch_bounds__(256) void generate_kernel(int kind, u64 seed, u64 n
             }
         } else {
             for (int j = 0; j < 8; j++) {
-                const u64 z = splitmix_at(seed, o + j + 1);
+                const u64 z = splitmix_at(seed, (kind == 3 ? text_resolve(seed, o + j) : o + j) + 1);
                 const u64 u = ((z >> 32) * W) >> 32;
                 int lo = 0, hi = 95;
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (u < cum[mid]) hi = mid; else lo = mid + 1; }
@@ -62,7 +85,7 @@ __global__ __launch_bounds__(256) void generate_kernel(int kind, u64 seed, u64 n
 
 int generate_device_impl(bwts_ctx *ctx, int kind, u64 seed, u64 n, u8 *d_out)
 {
-    if (kind < 0 || kind > 2) return BWTS_E_ARG;
+    if (kind < 0 || kind > 3) return BWTS_E_ARG;
     u64 blocks = (n / 8 + 256) / 256;
     if (blocks > 8192) blocks = 8192;
     generate_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(kind, seed, n, d_out);

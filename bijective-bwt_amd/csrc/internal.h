@@ -5,6 +5,9 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <vector>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "../../include/bwts.h"
 
@@ -17,6 +20,28 @@ struct TimedSpan {
     int cls;
     hipEvent_t a, b;
 };
+
+// Host-side copy workers for the host-buffer entry points: a chunk is cut into page-aligned parts and every worker (and the
+// caller) memcpy's one.  One thread moves ~10 GB/s into or out of pinned staging -- and pays every first-touch page fault
+// of a fresh output buffer alone -- which is below what the PCIe link carries.
+struct CopyPool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    u64 generation = 0;
+    int pending = 0;
+    bool stop = false;
+    char *dst = nullptr;
+    const char *src = nullptr;
+    size_t len = 0;
+    int parts = 1;
+    void start(int threads);
+    void copy(void *dst, const void *src, size_t len);      // returns when all parts are done
+    void shutdown();
+    void part(int i);
+};
+
+#define STAGE_SLOTS 4
 
 struct bwts_ctx {
     int device;
@@ -33,16 +58,25 @@ struct bwts_ctx {
     u64 *h_small;          // 4096 u64
     u64 *d_small;          // 4096 u64
 
-    // pinned staging for host-buffer entry points
-    char  *pinned[2];
+    // host-buffer entry points: pinned staging ring with one event per slot, copy workers, device-side in/out buffers
+    // that stay with the context, and the pinned blocks handed out by bwts_host_alloc
+    char  *pinned[STAGE_SLOTS];
+    hipEvent_t slot_ev[STAGE_SLOTS];
     size_t pinned_cap;
+    CopyPool *pool;
+    u8    *d_io[2];
+    size_t d_io_cap[2];
+    std::vector<std::pair<char *, size_t>> host_blocks;
 
     // event pool + spans of the current call
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used;
     std::vector<TimedSpan> spans;
     hipEvent_t ev_begin, ev_end;
-    bool timing;
+    int timing;            // HIP-event spans: 0 none (counters only), 1 dominant kernels, 2 all (bwts_set_timing / BWTS_TIMINGS=1)
+
+    // kernels that were granted more than 64 KB of dynamic LDS on this context's device (the attribute is per device)
+    std::vector<const void *> lds_granted;
 
     bwts_timings tm;
 };
@@ -69,6 +103,9 @@ template <typename T> static inline T *arena_array(bwts_ctx *ctx, u64 count)
 {
     return (T *)arena_alloc(ctx, (size_t)count * sizeof(T));
 }
+
+// opt-in for > 64 KB of dynamic LDS, once per kernel and context (a context is bound to one device)
+int ensure_dyn_lds(bwts_ctx *ctx, const void *kernel, size_t bytes);
 
 // ---- timing ------------------------------------------------------------------
 int  span_begin(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes);   // returns a span handle (spans may nest)

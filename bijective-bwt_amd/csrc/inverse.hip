@@ -695,14 +695,9 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
         if (mark == MARK_LOG) {
             HIPC(hipMemsetAsync(bucket_fill, 0, (size_t)nbuckets * IDX_FILL_STRIDE * sizeof(u32), ctx->stream));
-            static bool attr_set = false;
             const int bm_bytes = (int)((1u << IDX_RANGE_LOG2) / 8);
-            if (!attr_set) {
-                HIPC(hipFuncSetAttribute((const void *)unvisited_from_buckets_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bm_bytes));
-                HIPC(hipFuncSetAttribute((const void *)bucket_indices_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)bucket_indices_lds_bytes(IDX_MAX_BUCKETS)));
-                attr_set = true;
-            }
+            BWTS_TRY(ensure_dyn_lds(ctx, (const void *)unvisited_from_buckets_kernel, (size_t)bm_bytes));
+            BWTS_TRY(ensure_dyn_lds(ctx, (const void *)bucket_indices_kernel, bucket_indices_lds_bytes(IDX_MAX_BUCKETS)));
             bucket_deficit_kernel<<<dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream>>>(bucket_seen, nbuckets, n, deficient);
             bucket_indices_kernel<<<dim3((unsigned)log_chunks), dim3(IDX_THREADS), bucket_indices_lds_bytes(nbuckets), ctx->stream>>>(
                 idxlog, chunk_fill, nbuckets, deficient, bucket_fill, bucket_data);

@@ -565,11 +565,7 @@ template <bool FIRST, bool OUT_WIDE, bool HI16>
 static int launch_scatter_packed(bwts_ctx *ctx, u64 tiles, const PackedIO &io, const u32 *tile_off, u64 m, int shift)
 {
     constexpr size_t lds = (size_t)8192 * 9 + 2048 + 64 + (size_t)8 * 512;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPC(hipFuncSetAttribute((const void *)radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    BWTS_TRY(ensure_dyn_lds(ctx, (const void *)radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16>, lds));
     radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16><<<dim3((unsigned)rx_grid(tiles)), dim3(512), lds, ctx->stream>>>(io, tile_off, m, shift);
     return BWTS_OK;
 }
@@ -714,11 +710,7 @@ static int launch_scatter2_t(bwts_ctx *ctx, u64 tiles, const u64 *kin, const u32
                              u64 m, int shift, const u8 *sin = nullptr, u8 *sout = nullptr)
 {
     constexpr size_t lds = (size_t)TH * IT * 9 + 2048 + 64 + (size_t)(TH / 64) * 512;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPC(hipFuncSetAttribute((const void *)radix_scatter2_kernel<TH, IT, MINW, HAS_SYM, IDENT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    BWTS_TRY(ensure_dyn_lds(ctx, (const void *)radix_scatter2_kernel<TH, IT, MINW, HAS_SYM, IDENT>, lds));
     radix_scatter2_kernel<TH, IT, MINW, HAS_SYM, IDENT><<<dim3((unsigned)rx_grid(tiles)), dim3(TH), lds, ctx->stream>>>(kin, vin, kout, vout, tile_off, m, shift, sin, sout);
     return BWTS_OK;
 }

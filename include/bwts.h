@@ -35,6 +35,7 @@ extern "C" {
 #define BWTS_E_HIP      -4   /* a HIP runtime call failed; see bwts_last_hip_error() */
 #define BWTS_E_RANGE    -5   /* n beyond what the engine indexes (n > 2^32) */
 #define BWTS_E_INTERNAL -6   /* engine invariant violated (bug) */
+#define BWTS_E_SINK     -7   /* the caller's output sink returned nonzero */
 
 typedef struct bwts_ctx bwts_ctx;
 
@@ -57,6 +58,8 @@ enum {
     BWTS_K_COUNT
 };
 
+#define BWTS_MAX_ROUND_STATS 40
+
 typedef struct bwts_kernel_stat {
     double   ms;         /* summed device time of this class in the last call            */
     uint64_t launches;   /* number of launches                                           */
@@ -75,6 +78,7 @@ typedef struct bwts_timings {
     uint32_t key_bits;            /* bits of a round-0 key                                */
     uint64_t active_after_round0; /* elements still tied after round 0                    */
     uint64_t unvisited;           /* inverse: elements in cycles without a splitter       */
+    uint64_t round_active[BWTS_MAX_ROUND_STATS]; /* forward: elements still tied when sort round r+1 starts (r = 0: after round 0) */
     bwts_kernel_stat k[BWTS_K_COUNT];
 } bwts_timings;
 
@@ -86,34 +90,38 @@ void bwts_ctx_destroy(bwts_ctx *ctx);
 int bwts_forward(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out);
 int bwts_inverse(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out);
 
+/* Same transforms, the result handed to a callback in consecutive pieces (in order, together n bytes) straight from the
+ * pinned staging buffers: a CLI passes an fwrite wrapper and never holds an n-byte output buffer (mk_bwts_sa.c:60,
+ * unbwts.c:173).  A nonzero return of the sink aborts the call with BWTS_E_SINK. */
+typedef int (*bwts_sink_fn)(void *user, const uint8_t *data, uint64_t len);
+int bwts_forward_sink(bwts_ctx *ctx, const uint8_t *in, uint64_t n, bwts_sink_fn sink, void *user);
+int bwts_inverse_sink(bwts_ctx *ctx, const uint8_t *in, uint64_t n, bwts_sink_fn sink, void *user);
+
 /* Device-buffer entry points: d_in/d_out are device pointers on the context's
  * GPU (d_out may not alias d_in).  Synchronous: the call returns after the
  * result is complete in d_out. */
 int bwts_forward_device(bwts_ctx *ctx, const void *d_in, uint64_t n, void *d_out);
 int bwts_inverse_device(bwts_ctx *ctx, const void *d_in, uint64_t n, void *d_out);
 
-/* Statistics of the last forward/inverse call on this context. */
+/* Statistics of the last forward/inverse call on this context (see bwts_set_timing for the per-kernel times). */
 int bwts_last_timings(bwts_ctx *ctx, bwts_timings *t);
 const char *bwts_kernel_class_name(int k);
 
 const char *bwts_strerror(int code);
 int bwts_last_hip_error(bwts_ctx *ctx);          /* hipError_t of the last BWTS_E_HIP */
 
-/* Harness utilities (bench / tests): synthetic inputs of SURVEY.md 8(d) written
- * straight into device memory (kind 0 uniform256, 1 zipf, 2 dna), device
- * buffers without a tensor library, and a 64-bit FNV-style checksum. */
-int bwts_generate_device(bwts_ctx *ctx, int kind, uint64_t seed, uint64_t n, void *d_out);
-int bwts_device_alloc(bwts_ctx *ctx, uint64_t bytes, void **d_ptr);
-int bwts_device_free(bwts_ctx *ctx, void *d_ptr);
-int bwts_copy_to_device(bwts_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
-int bwts_copy_to_host(bwts_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
-int bwts_device_equal(bwts_ctx *ctx, const void *d_a, const void *d_b, uint64_t bytes, int *equal);
+/* Per-kernel HIP-event timing (bwts_timings.k[].ms) is off by default: ~400 event records per forward call cost
+ * about 1 ms at 1 GiB.  level 0 = off; 1 = only the dominant kernel of each direction (BWTS_K_RADIX_SCATTER_MAIN, BWTS_K_WALK:
+ * a handful of events); 2 = every class.  Applies to the following calls of this context; the launch / element / byte
+ * counters and total_ms are always filled.  A context created while BWTS_TIMINGS=1 is set starts at level 2
+ * (the reference's -DSHOW_TIMINGS, mk_bwts_sa.c:13-22). */
+int bwts_set_timing(bwts_ctx *ctx, int level);
 
-/* Unit-test hooks for single kernels (stable LSD radix sort of (u64 key, u32
- * value) pairs on the low key_bits bits; suffix array via the non-cyclic sort). */
-int bwts_debug_sort_pairs(bwts_ctx *ctx, uint64_t *h_keys, uint32_t *h_vals, uint64_t m, int key_bits);
-int bwts_debug_suffix_array(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint32_t *h_sa);
-int bwts_debug_lyndon(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint64_t *h_starts, uint64_t cap, uint64_t *count);
+/* Pinned host memory for callers that want the staging copy out of the way (the CLIs write their output straight
+ * from such a buffer): in/out of bwts_forward / bwts_inverse that lie inside a bwts_host_alloc block are transferred
+ * by DMA directly.  Optional: any host memory works. */
+int bwts_host_alloc(bwts_ctx *ctx, uint64_t bytes, void **h_ptr);
+int bwts_host_free(bwts_ctx *ctx, void *h_ptr);
 
 #ifdef __cplusplus
 }

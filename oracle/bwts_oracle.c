@@ -398,6 +398,35 @@ static const char zipf_alpha[] =
     "ETAOINSHRDLCUMWFGYPBVKJXQZ"
     "!$%*+?@\\^`{}~";
 
+/* kind 3, "text": the zipf stream with back-references -- the long repeats that real text has and an i.i.d. source lacks
+ * (the reference's only named workload is enwik8, Makefile:35-38, which is not in this image).
+ * Integer-only and seekable like the others.  For level l = 16 .. 4 the positions are cut into aligned windows of 2^l
+ * bytes; window w >= 1 of level l is a COPY when the low bits of h = splitmix(seed + l * TEXT_LEVEL_SALT, w) are zero
+ * (1 window in 8 for l = 4..7, 1 in 16 for l = 8..11, 1 in 32 for l = 12..16), and then its bytes equal the text at
+ * src + (p mod 2^l), src = (h >> 8) mod ((w - 1) * 2^l + 1): any earlier, unaligned offset.  A position is redirected
+ * through the largest copy window that holds it until it lies in none (every hop moves it towards 0); its byte is the
+ * zipf byte of that final position.  About 60 % of the text is copied material, with repeats of 16 B .. 64 KiB, nested. */
+#define TEXT_LEVEL_SALT 0xD1B54A32D192ED03ULL
+static inline uint64_t text_resolve(uint64_t seed, uint64_t p)
+{
+    int l = 16;
+    while (l >= 4) {
+        const uint64_t w = p >> l;
+        if (w) {
+            const uint64_t h = splitmix_at(seed + (uint64_t)l * TEXT_LEVEL_SALT, w);
+            const uint64_t mask = l < 8 ? 7u : l < 12 ? 15u : 31u;
+            if ((h & mask) == 0) {
+                const uint64_t span = ((w - 1) << l) + 1;
+                p = (h >> 8) % span + (p & (((uint64_t)1 << l) - 1));
+                l = 16;
+                continue;
+            }
+        }
+        l--;
+    }
+    return p;
+}
+
 void oracle_generate(int kind, uint64_t seed, uint64_t off, uint64_t len, uint8_t *dst)
 {
     uint64_t i;
@@ -416,7 +445,8 @@ void oracle_generate(int kind, uint64_t seed, uint64_t off, uint64_t len, uint8_
         int k;
         for (k = 0; k < 96; k++) { W += (1u << 24) / (uint64_t)(k + 1); cum[k] = W; }
         for (i = 0; i < len; i++) {
-            const uint64_t z = splitmix_at(seed, off + i + 1);
+            const uint64_t p = kind == 3 ? text_resolve(seed, off + i) : off + i;
+            const uint64_t z = splitmix_at(seed, p + 1);
             const uint64_t u = ((z >> 32) * W) >> 32;
             int lo = 0, hi = 95;
             while (lo < hi) { int mid = (lo + hi) / 2; if (u < cum[mid]) hi = mid; else lo = mid + 1; }

@@ -54,7 +54,8 @@ int oracle_inverse(const uint8_t *B, int64_t n, uint8_t *out);
  * returns the number of factors. */
 int64_t oracle_lyndon_starts(const uint8_t *T, int64_t n, int64_t *starts, int64_t cap);
 
-/* Synthetic inputs of SURVEY.md 8(d): kind 0 = uniform256, 1 = zipf, 2 = dna.
+/* Synthetic inputs of SURVEY.md 8(d): kind 0 = uniform256, 1 = zipf, 2 = dna; kind 3 = text (the zipf stream with
+ * back-references of 16 B .. 64 KiB: the repeat-rich stand-in for enwik8, defined at text_resolve() in the .c file).
  * Bytes [off, off+len) of the stream for the given seed (seekable). */
 void oracle_generate(int kind, uint64_t seed, uint64_t off, uint64_t len, uint8_t *dst);
 

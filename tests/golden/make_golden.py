@@ -52,6 +52,19 @@ def main():
                    "small": small, "large": large}, f, indent=0)
     print("wrote %d small + %d large vectors" % (len(small), len(large)))
 
+    # the input / golden pair of `make -C bijective-bwt_amd test` (the reference's Makefile:30-33 compares against
+    # testdata/testjunk.bwts, which it never shipped): 64 KiB of the text workload; the golden is the oracle's forward
+    # output, accepted only if the reference's own unbwts turns it back into the input
+    td_dir = os.path.join(os.path.dirname(os.path.dirname(HERE)), "bijective-bwt_amd", "testdata")
+    os.makedirs(td_dir, exist_ok=True)
+    x = O.generate("text", 1 << 16, 7)
+    y = O.forward(x)
+    with tempfile.TemporaryDirectory() as td:
+        assert np.array_equal(O.ref_unbwts(y, td), x)
+    x.tofile(os.path.join(td_dir, "testjunk"))
+    y.tofile(os.path.join(td_dir, "testjunk.bwts"))
+    print("wrote testdata/testjunk (+ .bwts)")
+
 
 if __name__ == "__main__":
     main()

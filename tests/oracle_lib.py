@@ -10,7 +10,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libbwts_oracle.so")
 REF_UNBWTS = os.path.join(ORACLE_DIR, "_ref", "unbwts")
 
-KINDS = {"uniform256": 0, "zipf": 1, "dna": 2}
+KINDS = {"uniform256": 0, "zipf": 1, "dna": 2, "text": 3}
 
 _lib = None
 

@@ -18,28 +18,31 @@ def built():
 
 
 def test_header_symbols_exported(built, pkg):
-    header = open(os.path.join(ROOT, "include", "bwts.h")).read()
-    declared = sorted(set(re.findall(r"\b(bwts_[a-z0-9_]+)\s*\(", header)))
-    assert declared, "no declarations parsed"
     L = pkg.lib()
-    missing = [s for s in declared if not hasattr(L, s)]
-    assert not missing, missing
-    assert sorted(pkg.EXPORTS) == declared
+    for name, listed in (("bwts.h", pkg.EXPORTS), ("bwts_test.h", pkg.TEST_EXPORTS)):
+        header = open(os.path.join(ROOT, "include", name)).read()
+        declared = sorted(set(re.findall(r"\b(bwts_[a-z0-9_]+)\s*\(", header)))
+        assert declared, "no declarations parsed"
+        missing = [s for s in declared if not hasattr(L, s)]
+        assert not missing, missing
+        assert sorted(listed) == declared
+    # the drop-in header carries no harness or debug entry points
+    assert not re.search(r"bwts_(debug|generate|device_alloc|copy_to)", open(os.path.join(ROOT, "include", "bwts.h")).read())
 
 
 def test_strerror_and_names(pkg):
     L = pkg.lib()
     assert L.bwts_strerror(0) == b"ok"
-    for code in range(-6, 0):
+    for code in range(-7, 0):
         assert L.bwts_strerror(code) and L.bwts_strerror(code) != b"unknown error"
     assert [L.bwts_kernel_class_name(i).decode() for i in range(pkg.K_COUNT)] == pkg.K_NAMES
 
 
 def test_timings_struct_layout_matches_header(pkg):
-    # bwts_timings: 3 doubles, 2 u64, 4 u32, 2 u64, then K_COUNT * (double + 3 u64)
+    # bwts_timings: 3 doubles, 2 u64, 4 u32, 2 u64, the per-round counts, then K_COUNT * (double + 3 u64)
     import ctypes
     assert ctypes.sizeof(pkg.KernelStat) == 32
-    assert ctypes.sizeof(pkg.Timings) == 3 * 8 + 2 * 8 + 4 * 4 + 2 * 8 + pkg.K_COUNT * 32
+    assert ctypes.sizeof(pkg.Timings) == 3 * 8 + 2 * 8 + 4 * 4 + 2 * 8 + pkg.MAX_ROUND_STATS * 8 + pkg.K_COUNT * 32
 
 
 def test_null_arguments_rejected(pkg):

@@ -10,10 +10,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(nproc, extra, port):
+def _launch(nproc, extra, port, gpus=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(nproc)] + extra
+           "--gpus", str(gpus or nproc)] + extra
     env = dict(os.environ, OMP_NUM_THREADS="1")
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300, cwd=ROOT)
 
@@ -31,6 +31,25 @@ def test_world_size_2_gloo():
     expect = 2 * (1 << 20) / 1e6 / (j["ms_per_step"] / 1e3)
     assert abs(j["value"] - expect) / expect < 0.01
     assert j["roundtrip_exact"] is True and "cpu_baseline" not in j
+
+
+def test_self_launch_without_outer_torchrun():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver may run it): bench.py starts its two ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log2n", "20",
+                        "--selftest-sleep-ms", "15", "--inverse-steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and 30.0 <= j["ms_per_step"] < 70.0
+
+
+def test_gpus_must_match_world_size():
+    r = _launch(2, ["--steps", "1", "--selftest-sleep-ms", "5"], 29579, gpus=3)
+    assert r.returncode != 0 and b"WORLD_SIZE=2" in r.stderr
 
 
 def test_single_process_selftest():

@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -352,7 +353,131 @@ def test_cli_end_to_end(tmp_path):
     env = dict(os.environ, BWTS_TIMINGS="1")
     r = _run_cli([os.path.join(PKG, "mk_bwts"), str(src), str(out)], env=env)
     labels = [l.split(" time ")[0] for l in r.stderr.decode().splitlines() if " time " in l]
-    assert labels[:4] == ["Suffix sort", "Compute ISA", "Fix sort order", "Generate BWTS"]           # mk_bwts_sa.c:50,124,168,190
+    assert labels[:5] == ["Suffix sort", "Compute ISA", "Fix sort order", "Generate BWTS", "Write BWTS"]   # mk_bwts_sa.c:50,124,168,190,62
+    assert out.read_bytes() == want
+    # the variant program the reference's `make test` drives: auto-named output (mk_bwts_new_algo.c:210-216)
+    r = _run_cli([os.path.join(PKG, "mk_bwts_new_algo"), str(src)])
+    assert r.returncode == 0
+    line = r.stdout.decode().strip()
+    assert line.startswith("Writing to %s_" % src) and line.endswith(".bwts")
+    assert open(line[len("Writing to "):], "rb").read() == want
+    r = _run_cli([os.path.join(PKG, "mk_bwts_new_algo")])
+    assert r.returncode == 1 and r.stderr.decode().splitlines()[1] == "If outfile is not supplied, a unique file name is generated"
+
+
+def test_make_test_prints_match():
+    """The reference's golden-file check (Makefile:30-33): mk_bwts_new_algo on testdata/testjunk, cmp, "Match"."""
+    proc = subprocess.Popen(["make", "-C", PKG, "test"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out, _ = proc.communicate(timeout=600)
+    time.sleep(1.0)
+    assert proc.returncode == 0, out.decode()[-2000:]
+    assert out.decode().strip().splitlines()[-1] == "Match" or "Match" in out.decode().splitlines()
+
+
+# ---------------------------------------------------------------------------------------------
+# host-buffer path (what the CLIs use): staging ring, copy workers, sink, pinned blocks
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 4095, (8 << 20) - 1, 8 << 20, (8 << 20) + 1, (40 << 20) + 12345])
+def test_host_path_sizes(ctx, n):
+    """Sizes around the staging chunk (8 MiB) and beyond the ring (4 slots): same bytes as the device path's oracle check."""
+    x = O.generate("zipf", n, 31)
+    want = O.forward(x) if n <= (8 << 20) + 1 else None
+    y = ctx.forward(x)
+    if want is not None:
+        assert np.array_equal(y, want)
+    assert np.array_equal(ctx.forward_sink(x), y)                 # same result through the sink callback
+    assert np.array_equal(ctx.inverse(y), x)
+    assert np.array_equal(ctx.inverse_sink(y), x)
+
+
+def test_host_path_pinned_blocks(ctx):
+    n = (9 << 20) + 77
+    x = O.generate("text", n, 4)
+    a, pa = ctx.host_alloc(n)
+    b, pb = ctx.host_alloc(n)
+    try:
+        a[:] = x
+        ctx.forward_into(a, b)                                    # both pinned: one DMA each way
+        y = b.copy()
+        assert np.array_equal(y, O.forward(x))
+        plain = np.empty(n, dtype=np.uint8)
+        ctx.forward_into(a, plain)                                # pinned in, pageable out
+        assert np.array_equal(plain, y)
+        ctx.inverse_into(y, a)                                    # pageable in, pinned out
+        assert np.array_equal(a, x)
+    finally:
+        del a, b
+        ctx.host_free(pa)
+        ctx.host_free(pb)
+
+
+def test_sink_error_aborts(ctx, pkg):
+    import ctypes
+    x = O.generate("zipf", 100000, 2)
+    cb = pkg.SINK_FN(lambda user, ptr, length: 1)
+    assert pkg.lib().bwts_forward_sink(ctx._h, x.ctypes.data, x.size, cb, None) == -7
+    assert np.array_equal(ctx.forward(x), O.forward(x))           # the context is still usable
+
+
+def test_two_contexts_one_process(pkg):
+    """Contexts are independent (bwts.h): two on device 0 back to back and interleaved -- and one per device when the box has
+    more than one.  Every context opts its own kernels into > 64 KB of LDS."""
+    import torch
+    x = O.generate("zipf", 1 << 20, 41)                           # large enough for the packed round-0 passes
+    z = O.generate("text", 1 << 20, 42)                           # dense ranks: the binned rank build's large-LDS kernels
+    wx, wz = O.forward(x), O.forward(z)
+    devs = [0, 0] + ([1] if torch.cuda.device_count() > 1 else [])
+    ctxs = [pkg.Context(d) for d in devs]
+    try:
+        for c in ctxs:
+            assert np.array_equal(c.forward(x), wx)
+        for c in reversed(ctxs):
+            assert np.array_equal(c.forward(z), wz)
+            assert np.array_equal(c.inverse(wz), z)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_timing_is_opt_in(ctx):
+    x = O.generate("zipf", 1 << 20, 5)
+    ctx.set_timing(0)
+    ctx.forward(x)
+    t = ctx.timings().as_dict()
+    assert t["total_ms"] > 0 and t["kernels"]["radix_scatter"]["launches"] > 0 and t["kernels"]["radix_scatter"]["ms"] == 0
+    ctx.set_timing(2)
+    ctx.forward(x)
+    t = ctx.timings().as_dict()
+    assert t["kernels"]["radix_scatter"]["ms"] > 0
+    ctx.set_timing(0)
+
+
+# ---------------------------------------------------------------------------------------------
+# repeat-rich text (SURVEY 8 f4; the reference's named workload is enwik8, Makefile:35-38)
+# ---------------------------------------------------------------------------------------------
+def test_text_generator_matches_oracle(ctx):
+    n = (1 << 22) + 3
+    d = ctx.alloc(n)
+    try:
+        ctx.generate("text", 9, n, d)
+        assert hashlib.sha256(d.download().tobytes()).hexdigest() == hashlib.sha256(O.generate("text", n, 9).tobytes()).hexdigest()
+    finally:
+        d.free()
+
+
+def test_text_16MiB_vs_oracle(ctx):
+    """16 MiB of the text workload: most positions tied after round 0, a dozen doubling rounds."""
+    n = 1 << 24
+    x = O.generate("text", n, 1)
+    y = ctx.forward(x)
+    t = ctx.timings()
+    assert t.active_after_round0 > n // 4 and t.rounds >= 8
+    assert hashlib.sha256(y.tobytes()).hexdigest() == hashlib.sha256(O.forward(x).tobytes()).hexdigest()
+    assert np.array_equal(ctx.inverse(y), x)
+
+
+def test_text_1GiB_properties(ctx):
+    _properties_at_scale(ctx, "text", 1 << 30, 1)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -35,9 +35,32 @@ def test_generator_matches_survey():
     assert [hex(int(v)) for v in z] == KAT["generator_first_outputs_seed1"]
     assert O.generate("dna", 32, 1).tobytes() == b"CAATATCCGAAACGAGATGTCTGAGGAACACG"
     # seekable: a slice of the stream equals the stream's slice
-    for kind in ("uniform256", "zipf", "dna"):
+    for kind in ("uniform256", "zipf", "dna", "text"):
         full = O.generate(kind, 1000, 5)
         assert np.array_equal(O.generate(kind, 300, 5, off=123), full[123:423])
+
+
+def test_text_generator_pinned():
+    """The repeat-rich text workload (oracle_generate kind 3): stream hash pinned, seekable deep into the stream, and the
+    oracle's forward output on it accepted by the reference's own inverse (live, where oracle/_ref/unbwts exists)."""
+    x = O.generate("text", 1 << 20, 1)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == "514bc95e4ca70b19bda5d6208945e12f666b52bcd760947f253559966bfc697d"
+    assert np.array_equal(O.generate("text", 5000, 1, off=(1 << 20) - 5000), x[-5000:])
+    y = O.forward(x)
+    assert hashlib.sha256(y.tobytes()).hexdigest() == "58d139d1e7171e490c03786bff466c093ecae4e5a7754efe5f5613f99f019716"
+    assert np.array_equal(O.inverse(y), x)
+    if O.have_ref_unbwts():
+        with tempfile.TemporaryDirectory() as td:
+            assert np.array_equal(O.ref_unbwts(y, td), x)
+
+
+def test_make_test_golden_is_the_oracles():
+    """bijective-bwt_amd/testdata/testjunk.bwts (what `make test` compares the CLI's output with) is oracle_forward(testjunk)."""
+    td = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bijective-bwt_amd", "testdata")
+    x = np.fromfile(os.path.join(td, "testjunk"), dtype=np.uint8)
+    y = np.fromfile(os.path.join(td, "testjunk.bwts"), dtype=np.uint8)
+    assert x.size == y.size == 1 << 16
+    assert np.array_equal(O.forward(x), y) and np.array_equal(O.inverse(y), x)
 
 
 def test_known_answers():
