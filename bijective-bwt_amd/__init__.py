@@ -56,7 +56,7 @@ class Timings(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_double), ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
                 ("n", ctypes.c_uint64), ("factors", ctypes.c_uint64), ("rounds", ctypes.c_uint32),
                 ("lyndon_rounds", ctypes.c_uint32), ("key_symbols", ctypes.c_uint32), ("key_bits", ctypes.c_uint32),
-                ("active_after_round0", ctypes.c_uint64), ("unvisited", ctypes.c_uint64),
+                ("active_after_round0", ctypes.c_uint64), ("unvisited", ctypes.c_uint64), ("device_bytes", ctypes.c_uint64),
                 ("round_active", ctypes.c_uint64 * MAX_ROUND_STATS), ("k", KernelStat * K_COUNT)]
 
     def as_dict(self):

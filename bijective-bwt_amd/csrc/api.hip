@@ -36,18 +36,18 @@ void *arena_alloc(bwts_ctx *ctx, size_t bytes)
     return p;
 }
 
-int aux_reserve(bwts_ctx *ctx, size_t bytes, char **base)
+int aux_reserve_slot(bwts_ctx *ctx, int slot, size_t bytes, char **base)
 {
     bytes = align_up(bytes, 1 << 20);
-    if (bytes > ctx->aux_cap) {
-        // contents of a previous, smaller aux block are never live across this call
-        if (ctx->aux) { HIPC(hipStreamSynchronize(ctx->stream)); HIPC(hipFree(ctx->aux)); ctx->aux = nullptr; ctx->aux_cap = 0; }
+    if (bytes > ctx->aux_cap[slot]) {
+        // contents of a previous, smaller block are never live across this call
+        if (ctx->aux[slot]) { HIPC(hipStreamSynchronize(ctx->stream)); HIPC(hipFree(ctx->aux[slot])); ctx->aux[slot] = nullptr; ctx->aux_cap[slot] = 0; }
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
-        ctx->aux = (char *)p;
-        ctx->aux_cap = bytes;
+        ctx->aux[slot] = (char *)p;
+        ctx->aux_cap[slot] = bytes;
     }
-    *base = ctx->aux;
+    *base = ctx->aux[slot];
     return BWTS_OK;
 }
 
@@ -153,7 +153,7 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->arena) (void)hipFree(ctx->arena);
-    if (ctx->aux) (void)hipFree(ctx->aux);
+    for (int i = 0; i < 2; i++) if (ctx->aux[i]) (void)hipFree(ctx->aux[i]);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
@@ -186,6 +186,7 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
     float ms = 0.f;
     HIPC(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     ctx->tm.total_ms = ms;
+    ctx->tm.device_bytes = ctx->arena_cap + ctx->aux_cap[0] + ctx->aux_cap[1] + ctx->d_io_cap[0] + ctx->d_io_cap[1];
     return BWTS_OK;
 }
 
@@ -266,6 +267,40 @@ void CopyPool::shutdown()
     workers.clear();
 }
 
+// Copies between HBM and pinned host memory by a kernel instead of the DMA engines: the SDMA path moved 29-30 GB/s from the
+// device to the host on the MI355X boxes used here, stores issued by compute units reach the PCIe link's rate.
+__global__ __launch_bounds__(256) void pcie_copy_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, u64 vecs,
+                                                        u8 *__restrict__ dst_tail, const u8 *__restrict__ src_tail, u32 tail)
+{
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < vecs; i += (u64)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+static int copy_mode(const char *name)      // 0 = DMA engine (hipMemcpyAsync), 1 = copy kernel
+{
+    const char *e = getenv(name);
+    if (e && !strcmp(e, "dma")) return 0;
+    if (e && !strcmp(e, "kernel")) return 1;
+    return -1;
+}
+
+static int pcie_copy(bwts_ctx *ctx, void *dst, const void *src, size_t len, bool use_kernel, hipMemcpyKind kind)
+{
+    if (!use_kernel || (((uintptr_t)dst | (uintptr_t)src) & 15)) {
+        HIPC(hipMemcpyAsync(dst, src, len, kind, ctx->stream));
+        return BWTS_OK;
+    }
+    const u64 vecs = len / 16;
+    const u32 tail = (u32)(len % 16);
+    u64 blocks = (vecs + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    pcie_copy_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>((uint4 *)dst, (const uint4 *)src, vecs, (u8 *)dst + vecs * 16,
+                                                                            (const u8 *)src + vecs * 16, tail);
+    HIPC(hipGetLastError());
+    return BWTS_OK;
+}
+
 static int ensure_staging(bwts_ctx *ctx)
 {
     for (int i = 0; i < STAGE_SLOTS; i++) {
@@ -298,8 +333,10 @@ static bool is_pinned_block(const bwts_ctx *ctx, const void *p, u64 n)
 
 static int staged_h2d(bwts_ctx *ctx, u8 *d_dst, const u8 *h_src, u64 n)
 {
+    static const int mode = copy_mode("BWTS_H2D");
+    const bool by_kernel = mode == 1;
     if (is_pinned_block(ctx, h_src, n)) {
-        HIPC(hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, ctx->stream));
+        BWTS_TRY(pcie_copy(ctx, d_dst, h_src, n, by_kernel, hipMemcpyHostToDevice));
         HIPC(hipStreamSynchronize(ctx->stream));
         return BWTS_OK;
     }
@@ -310,7 +347,7 @@ static int staged_h2d(bwts_ctx *ctx, u8 *d_dst, const u8 *h_src, u64 n)
         const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
         if (c >= STAGE_SLOTS) HIPC(hipEventSynchronize(ctx->slot_ev[slot]));       // the slot's previous DMA has read it
         ctx->pool->copy(ctx->pinned[slot], h_src + off, len);
-        HIPC(hipMemcpyAsync(d_dst + off, ctx->pinned[slot], len, hipMemcpyHostToDevice, ctx->stream));
+        BWTS_TRY(pcie_copy(ctx, d_dst + off, ctx->pinned[slot], len, by_kernel, hipMemcpyHostToDevice));
         HIPC(hipEventRecord(ctx->slot_ev[slot], ctx->stream));
         off += len;
     }
@@ -321,8 +358,10 @@ static int staged_h2d(bwts_ctx *ctx, u8 *d_dst, const u8 *h_src, u64 n)
 // the result leaves in consecutive pieces: to h_dst (copy workers), or to the caller's sink straight from the staging slot
 static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n, bwts_sink_fn sink, void *user)
 {
+    static const int mode = copy_mode("BWTS_D2H");
+    const bool by_kernel = mode != 0;              // default: copy kernel
     if (!sink && is_pinned_block(ctx, h_dst, n)) {
-        HIPC(hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
+        BWTS_TRY(pcie_copy(ctx, h_dst, d_src, n, by_kernel, hipMemcpyDeviceToHost));
         HIPC(hipStreamSynchronize(ctx->stream));
         return BWTS_OK;
     }
@@ -332,7 +371,7 @@ static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n, bwts_sin
         const u64 off = c * STAGE_CHUNK;
         const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
         const int slot = (int)(c % STAGE_SLOTS);
-        HIPC(hipMemcpyAsync(ctx->pinned[slot], d_src + off, len, hipMemcpyDeviceToHost, ctx->stream));
+        BWTS_TRY(pcie_copy(ctx, ctx->pinned[slot], d_src + off, len, by_kernel, hipMemcpyDeviceToHost));
         HIPC(hipEventRecord(ctx->slot_ev[slot], ctx->stream));
         return BWTS_OK;
     };

@@ -1074,6 +1074,8 @@ struct SortSpace {
     u64 tie_count = 0;
     // the cyclic sort will carry the byte stream (=> the packed passes may apply); keys[0] currently holds split keys
     bool want_split = false, split_keys = false;
+    // set by the sort when the later rounds wrote the bytes of the tied elements themselves (dense rounds)
+    bool ties_emitted = false;
 };
 
 static size_t sort_space_bytes(u64 n)
@@ -1295,6 +1297,270 @@ __global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restric
     }
 }
 
+// ---- later rounds with the dense rank array: group-local rounds -------------------------------------------------------
+// Real text ties most positions after round 0 and keeps them tied for a dozen rounds (a position inside a repeat of
+// length R leaves only when the step reaches R), while nearly all of its groups are small -- the two or three copies of a
+// phrase.  A round then has to cost little per tied element.  The tied list stays group-contiguous (idx = position,
+// head = first slot of the group = current rank), but its order is free, SA is not maintained (final ranks say
+// everything), and one kernel does a whole round for every group of at most DG_CAP elements:
+//   gather r = rank[successor] -> order the members by r (LDS, counting) -> subgroups of equal r: new head = head + number
+//   of smaller members -> members that are alone are finished: their rank is final and their output byte is written;
+//   the others stay, with their new head.  rank[] is updated in place: a successor rank read in the same round may already
+//   be refined, which orders at least as finely as the unrefined one and never differently (ranks only ever split).
+// Larger groups (a few per cent of the elements after the first rounds) are flagged, compacted, ordered by the radix
+// sort, regrouped with a scan and put back.  A stable compaction of the surviving elements gives the next round's list.
+#define DG_CAP     16
+#define DG_THREADS 256
+#define DG_ITEMS   8
+#define DG_TILE    (DG_THREADS * DG_ITEMS)
+#define DG_SPAN    (DG_TILE + 2 * DG_CAP + 1)   // + 1: the slot that shows where a group ending at the last tail slot ends
+#define DG_FS_LDS  1024                  // factor starts kept in LDS when there are at most this many
+enum { DG_DONE = 0, DG_KEEP = 1, DG_BIG = 2, DG_MOVED = 4 };      // state: low bits = what happens to the element; DG_MOVED: its head (= rank) changed
+
+struct PrevSym {       // T[cprev(p)] (mk_bwts_sa.c:172-188): from the P array when one was built, else through the factor list
+    const u8 *P; const u8 *T; u64 n; const u32 *fstart; u64 k;
+    __device__ __forceinline__ u8 operator()(u64 p) const
+    {
+        if (P) return P[p];
+        if (!fstart) return p ? T[p - 1] : T[n - 1];
+        const u64 f = factor_of(fstart, k, p);
+        return fstart[f] == p ? T[factor_end(fstart, k, n, f) - 1] : T[p - 1];
+    }
+};
+
+// counters: [1] elements of larger groups, [2] a group split.  rank[] is only read here: the new ranks are applied by the
+// compaction pass at the end of the round (DgKeepOut) -- a round's keys must all come from the same version of the ranks:
+// a member that already shows its new rank next to a group-mate that still shows the old one would order the wrong way.
+template <bool CYCLIC>
+__global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, u64 a,
+                                                                 const u32 *__restrict__ rank, u64 n, u64 h,
+                                                                 const u32 *__restrict__ fstart, u64 k,
+                                                                 u32 *__restrict__ oidx, u32 *__restrict__ ohead, u8 *__restrict__ state,
+                                                                 PrevSym prev, u8 *__restrict__ out /* null: no emission */,
+                                                                 unsigned long long *__restrict__ counters)
+{
+    __shared__ u32 hd[DG_SPAN];          // group heads of the tile and DG_CAP elements on either side
+    __shared__ u32 key[DG_SPAN];         // successor ranks of the members of the groups this tile owns
+    __shared__ u32 fs[DG_FS_LDS];
+    __shared__ u32 cnt_big, any_split;
+    const int tid = threadIdx.x;
+    const u64 base = (u64)blockIdx.x * DG_TILE;              // list index of LDS slot DG_CAP
+    if (tid == 0) { cnt_big = 0; any_split = 0; }
+    const bool fs_lds = CYCLIC && k <= DG_FS_LDS;
+    if (fs_lds) for (u32 i = tid; i < k; i += DG_THREADS) fs[i] = fstart[i];
+    for (u32 sl = tid; sl < DG_SPAN; sl += DG_THREADS) {
+        const long long e = (long long)base - DG_CAP + sl;
+        hd[sl] = (e >= 0 && (u64)e < a) ? head[e] : 0xffffffffu;       // outside the list: never equal to a neighbour's head? see below
+    }
+    __syncthreads();
+    // slot sl holds list element e = base - DG_CAP + sl.  Elements outside [0, a) must not join a group: heads are slots
+    // < n <= 2^32 - 1 except for n = 2^32, so equality is tested together with the bounds.
+    auto same = [&](u32 x, u32 y) -> bool {       // do slots x and y (adjacent) belong to one group?
+        const long long ex = (long long)base - DG_CAP + x, ey = (long long)base - DG_CAP + y;
+        return ex >= 0 && ey >= 0 && (u64)ex < a && (u64)ey < a && hd[x] == hd[y];
+    };
+    // every thread looks after DG_ITEMS slots of [DG_CAP, DG_CAP + DG_TILE + DG_CAP): the tile's own elements and the
+    // DG_CAP behind them (members of an owned group may reach that far)
+    u32 my_idx[DG_ITEMS + 1], my_gs[DG_ITEMS + 1];
+    u8 my_sz[DG_ITEMS + 1], my_kind[DG_ITEMS + 1];            // kind: 0 nothing to do here, 1 member of an owned small group, 2 own element of a large group
+#pragma unroll
+    for (int j = 0; j <= DG_ITEMS; j++) {
+        my_kind[j] = 0; my_idx[j] = 0; my_gs[j] = 0; my_sz[j] = 0;
+        // slots DG_CAP + j * DG_THREADS + tid; the extra round (j == DG_ITEMS) covers the DG_CAP slots behind the tile
+        const u32 sl = DG_CAP + (u32)j * DG_THREADS + tid;
+        if (j == DG_ITEMS && tid >= DG_CAP) continue;
+        const u64 e = base + (u64)(sl - DG_CAP);
+        if (e >= a) continue;
+        // group start: walk back while the neighbour belongs to the same group (at most DG_CAP steps)
+        u32 gs = sl, steps = 0;
+        while (steps < DG_CAP && gs > 0 && same(gs - 1, gs)) { gs--; steps++; }
+        const bool start_seen = gs > 0 && !same(gs - 1, gs);
+        u32 ge = sl + 1;                                       // one past the last member seen
+        steps = 0;
+        while (steps < DG_CAP && ge < DG_SPAN && same(ge - 1, ge)) { ge++; steps++; }
+        const bool end_seen = ge < DG_SPAN && !same(ge - 1, ge);
+        const bool small = start_seen && end_seen && ge - gs <= DG_CAP;
+        const bool own_elem = sl < DG_CAP + DG_TILE;
+        if (small) {
+            if (gs >= DG_CAP && gs < DG_CAP + DG_TILE) { my_kind[j] = 1; my_gs[j] = gs; my_sz[j] = (u8)(ge - gs); }
+        } else if (own_elem) my_kind[j] = 2;
+        if (my_kind[j]) my_idx[j] = idx[e];
+    }
+    // successor ranks of the owned members: all of a thread's gathers are in flight together
+    u32 my_key[DG_ITEMS + 1];
+#pragma unroll
+    for (int j = 0; j <= DG_ITEMS; j++) {
+        my_key[j] = 0;
+        if (my_kind[j] != 1) continue;
+        const u64 p = my_idx[j];
+        if (CYCLIC) {
+            u64 f;
+            if (fs_lds) {
+                u64 lo = 0, hi = k - 1;
+                while (lo < hi) { const u64 mid = (lo + hi + 1) >> 1; if ((u64)fs[mid] <= p) lo = mid; else hi = mid - 1; }
+                f = lo;
+            } else f = factor_of(fstart, k, p);
+            const u64 s0 = fs_lds ? fs[f] : fstart[f];
+            const u64 e0 = f + 1 < k ? (u64)(fs_lds ? fs[f + 1] : fstart[f + 1]) : n;
+            my_key[j] = rank[cyclic_successor(p, s0, e0 - s0, h)];
+        } else {
+            const u64 q = p + h;
+            my_key[j] = q < n ? rank[q] + 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j <= DG_ITEMS; j++)
+        if (my_kind[j] == 1) key[DG_CAP + (u32)j * DG_THREADS + tid] = my_key[j];
+    __syncthreads();
+    u32 big_here = 0, split_here = 0;
+#pragma unroll
+    for (int j = 0; j <= DG_ITEMS; j++) {
+        const u32 sl = DG_CAP + (u32)j * DG_THREADS + tid;
+        const u64 e = base + (u64)(sl - DG_CAP);
+        if (my_kind[j] == 2) { oidx[e] = my_idx[j]; ohead[e] = hd[sl]; state[e] = DG_BIG; big_here++; }
+        if (my_kind[j] != 1) continue;
+        const u32 gs = my_gs[j], sz = my_sz[j], mine = my_key[j];
+        u32 less = 0, eq = 0, eq_before = 0;
+        for (u32 m = 0; m < sz; m++) {
+            const u32 ko = key[gs + m];
+            less += ko < mine ? 1u : 0u;
+            eq += ko == mine ? 1u : 0u;
+            eq_before += (ko == mine && gs + m < sl) ? 1u : 0u;
+        }
+        const u32 oldhead = hd[sl], newhead = oldhead + less;
+        const u64 dst = base + (u64)(gs - DG_CAP) + less + eq_before;
+        const bool alone = eq == 1;
+        oidx[dst] = my_idx[j]; ohead[dst] = newhead; state[dst] = (u8)((alone ? DG_DONE : DG_KEEP) | (less ? DG_MOVED : 0));
+        if (alone && out) out[newhead] = prev(my_idx[j]);
+        split_here |= eq < sz ? 1u : 0u;
+    }
+    if (big_here) atomicAdd(&cnt_big, big_here);
+    if (split_here) any_split = 1;
+    __syncthreads();
+    if (tid == 0) {
+        if (cnt_big) atomicAdd(&counters[1], (unsigned long long)cnt_big);
+        if (any_split && __hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(&counters[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// larger groups: compaction with the successor-rank gather.  Scan value: low word = flagged elements, high word = flagged
+// groups (their first elements) before the position; the compacted key carries the group's ordinal among the flagged groups
+// and the successor rank.
+struct DgBigIn {
+    const u8 *state; const u32 *head;
+    __device__ __forceinline__ u64 operator()(u64 i) const
+    {
+        const u32 f = (state[i] & 3) == DG_BIG ? 1u : 0u;
+        const u32 st = f && (i == 0 || head[i] != head[i - 1] || (state[i - 1] & 3) != DG_BIG) ? 1u : 0u;
+        return ((u64)st << 32) | f;
+    }
+};
+template <bool CYCLIC>
+struct DgBigOut {
+    const u8 *state; const u32 *head; const u32 *idx; u64 a; int rb; const u32 *rank; u64 n; u64 h; const u32 *fstart; u64 k;
+    u64 *bk; u32 *bv; u32 *bpos;
+    __device__ __forceinline__ void operator()(u64 i, u64 before) const
+    {
+        if ((state[i] & 3) != DG_BIG) return;
+        const u32 st = (i == 0 || head[i] != head[i - 1] || (state[i - 1] & 3) != DG_BIG) ? 1u : 0u;
+        const u64 ord = (before >> 32) + st - 1;
+        const u32 at = (u32)before;
+        const u64 p = idx[i];
+        u64 r2;
+        if (CYCLIC) {
+            const u64 f = factor_of(fstart, k, p);
+            const u64 s0 = fstart[f], L = factor_end(fstart, k, n, f) - s0;
+            r2 = rank[cyclic_successor(p, s0, L, h)];
+        } else {
+            const u64 q = p + h;
+            r2 = q < n ? (u64)rank[q] + 1ull : 0ull;
+        }
+        bk[at] = (ord << rb) | r2;
+        bv[at] = (u32)p;
+        bpos[at] = (u32)i;
+    }
+};
+// regrouping of the sorted larger groups.  Scan value (max on both halves): high word = 1 + index of the element's group
+// start, low word = 1 + index of its subgroup start, both in the sorted compacted order.
+struct OpMax2 {
+    template <typename T> __device__ __forceinline__ T operator()(T x, T y) const
+    {
+        const u32 xh = (u32)(x >> 32), yh = (u32)(y >> 32), xl = (u32)x, yl = (u32)y;
+        return ((u64)(xh > yh ? xh : yh) << 32) | (u64)(xl > yl ? xl : yl);
+    }
+};
+struct DgRegroupIn {
+    const u64 *bk; u64 m; int rb;
+    __device__ __forceinline__ u64 operator()(u64 j) const
+    {
+        const u64 kj = bk[j];
+        const bool gstart = j == 0 || (bk[j - 1] >> rb) != (kj >> rb);
+        const bool sstart = gstart || bk[j - 1] != kj;
+        return ((u64)(gstart ? (u32)j + 1u : 0u) << 32) | (u64)(sstart ? (u32)j + 1u : 0u);
+    }
+};
+struct DgRegroupOut {
+    const u64 *bk; const u32 *bv; const u32 *bpos; u64 m; int rb;
+    u32 *oidx; u32 *ohead; u8 *state; PrevSym prev; u8 *out; unsigned long long *counters;
+    __device__ __forceinline__ void operator()(u64 j, u64 v) const       // inclusive scan value
+    {
+        const u32 gidx = (u32)(v >> 32) - 1u, sidx = (u32)v - 1u;
+        const u64 kj = bk[j];
+        const bool last_of_sub = j + 1 == m || bk[j + 1] != kj;
+        const bool alone = sidx == (u32)j && last_of_sub;
+        // the j-th flagged list slot: sorting keeps every group on its own slots, and all of them still hold the group's old head
+        const u32 at = bpos[j];
+        const u32 newhead = ohead[at] + (sidx - gidx);
+        const u32 p = bv[j];
+        oidx[at] = p; ohead[at] = newhead; state[at] = (u8)((alone ? DG_DONE : DG_KEEP) | (sidx != gidx ? DG_MOVED : 0));
+        if (alone && out) out[newhead] = prev(p);
+        const u64 splitm = __ballot(sidx != gidx);
+        if (splitm && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1 &&
+            __hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(&counters[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+// end of a round: the new ranks are written, the elements that stay are compacted (stable) into the next round's list
+struct DgKeepIn {
+    const u8 *state;
+    __device__ __forceinline__ u32 operator()(u64 i) const { return (state[i] & 3) == DG_KEEP ? 1u : 0u; }
+};
+struct DgKeepOut {
+    const u8 *state; const u32 *oidx; const u32 *ohead; u32 *rank; u32 *n_idx; u32 *n_head; u64 a; u64 *count;
+    __device__ __forceinline__ void operator()(u64 i, u32 before) const
+    {
+        const u32 st = state[i];
+        const bool keep = (st & 3) == DG_KEEP;
+        if ((st & DG_MOVED) || keep) {
+            const u32 p = oidx[i], hd = ohead[i];
+            if (st & DG_MOVED) rank[p] = hd;
+            if (keep) { n_idx[before] = p; n_head[before] = hd; }
+        }
+        if (i + 1 == a) *count = (u64)before + (keep ? 1u : 0u);
+    }
+};
+// what is left when no group splits any more: equal infinite words (mk_bwts_sa.c ties only between identical rotations, which
+// emit identical bytes).  The members of such a group take the group's slots in list order.
+struct DgRestIn {
+    const u32 *head;
+    __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || head[i] != head[i - 1]) ? (u32)i + 1u : 0u; }
+};
+struct DgRestOut {
+    const u32 *idx; const u32 *head; PrevSym prev; u8 *out; u32 *SA;
+    __device__ __forceinline__ void operator()(u64 i, u32 v) const       // inclusive max-scan: 1 + list index of the group's first element
+    {
+        const u32 slot = head[i] + ((u32)i - (v - 1u));
+        if (out) out[slot] = prev(idx[i]);
+        if (SA) SA[slot] = idx[i];
+    }
+};
+__global__ __launch_bounds__(256) void sa_from_rank_kernel(const u32 *__restrict__ rank, u64 n, u32 *__restrict__ SA)
+{
+    for (u64 p = (u64)blockIdx.x * 256 + threadIdx.x; p < n; p += (u64)gridDim.x * 256) SA[rank[p]] = (u32)p;
+}
+
 struct ActiveList { u32 *idx, *slot, *head; };
 
 static int build_ranks(bwts_ctx *ctx, const u32 *SA, u64 n, const ActiveList &l, u64 a, u32 *rank)
@@ -1304,6 +1570,109 @@ static int build_ranks(bwts_ctx *ctx, const u32 *SA, u64 n, const ActiveList &l,
     rank_from_sa_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(SA, n, rank);
     if (a) rank_from_list_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(l.idx, l.head, a, rank);
     HIPC(hipGetLastError());
+    return BWTS_OK;
+}
+
+// The rounds after round 0 when many elements are tied (dense rank array in sp.rank): see dense_round_kernel.
+// cur: the tied list left by round 0 (group-contiguous).  On return the ranks in sp.rank are final (members of a group
+// of equal infinite words share their group's first slot); with need_sa the suffix array is rebuilt from them.
+template <bool CYCLIC>
+static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, const u32 *d_fstart, u64 k, SortSpace &sp,
+                        ActiveList cur, u64 a, u32 *SA, bool need_sa, u32 *rounds_io)
+{
+    if (a > 0xffffffffull) return BWTS_E_NOMEM;     // every position tied at n = 2^32: beyond what the side buffers hold
+    u64 *cnt = ctx->d_small + SM_COUNTERS;
+    const size_t e4 = align_up((size_t)a * 4, 256), e1 = align_up((size_t)a, 256);
+    char *base = nullptr;
+    BWTS_TRY(aux_reserve(ctx, 6 * e4 + e1, &base));
+    u32 *t_idx = (u32 *)base, *t_head = (u32 *)(base + e4);
+    u8 *state = (u8 *)(base + 2 * e4);
+    ActiveList sets[2];
+    for (int i = 0; i < 2; i++) {
+        sets[i].idx = (u32 *)(base + 2 * e4 + e1 + (size_t)(2 * i) * e4);
+        sets[i].head = (u32 *)(base + 2 * e4 + e1 + (size_t)(2 * i + 1) * e4);
+        sets[i].slot = nullptr;
+    }
+    const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
+    PrevSym prev{sp.carry_src, d_T, n, d_fstart, k};
+    u8 *out = CYCLIC ? sp.carry_out : nullptr;
+    u32 rounds = *rounds_io;
+    int nxt = 0;
+    for (u64 h = (u64)al.hstep;; h <<= 1) {
+        rounds++;
+        HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
+        {
+            SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 29 * a);       // idx, head in; idx, head, state out; one rank gather
+            const unsigned blocks = (unsigned)((a + DG_TILE - 1) / DG_TILE);
+            dense_round_kernel<CYCLIC><<<dim3(blocks), dim3(DG_THREADS), 0, ctx->stream>>>(
+                cur.idx, cur.head, a, sp.rank, n, h, d_fstart, k, t_idx, t_head, state, prev, out, (unsigned long long *)cnt);
+            HIPC(hipGetLastError());
+        }
+        BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
+        const u64 m_big = ctx->h_small[SM_COUNTERS + 1];
+        if (m_big > a) return BWTS_E_INTERNAL;
+        if (m_big) {
+            // larger groups: compact (with the successor ranks), radix sort by (group ordinal, successor rank), regroup, put back
+            char *bb = nullptr;
+            const size_t m8 = align_up((size_t)m_big * 8, 256), m4 = align_up((size_t)m_big * 4, 256);
+            BWTS_TRY(aux_reserve_slot(ctx, 1, 2 * m8 + 3 * m4, &bb));
+            u64 *bk[2] = {(u64 *)bb, (u64 *)(bb + m8)};
+            u32 *bv[2] = {(u32 *)(bb + 2 * m8), (u32 *)(bb + 2 * m8 + m4)};
+            u32 *bpos = (u32 *)(bb + 2 * m8 + 2 * m4);
+            {
+                SpanGuard g(ctx, BWTS_K_RERANK, a, 10 * a + 20 * m_big);
+                DgBigIn fin{state, t_head};
+                DgBigOut<CYCLIC> fout{state, t_head, t_idx, a, rb, sp.rank, n, h, d_fstart, k, bk[0], bv[0], bpos};
+                BWTS_TRY((device_scan<false, u64>(ctx, a, fin, fout, OpAdd(), (u64)0, sp.scan_temp)));
+            }
+            SortPlan bp;
+            bp.keys[0] = bk[0]; bp.keys[1] = bk[1];
+            bp.vals[0] = bv[0]; bp.vals[1] = bv[1];
+            bp.tile_hist = sp.tile_hist; bp.scan_temp = sp.scan_temp;
+            int rbig = 0;
+            int big_bits = bitlen_u64(m_big / (DG_CAP + 1)) + rb;          // ordinals < m_big / (DG_CAP + 1)
+            if (big_bits > 64) return BWTS_E_RANGE;
+            BWTS_TRY(radix_sort_pairs(ctx, bp, m_big, big_bits, &rbig));
+            {
+                SpanGuard g(ctx, BWTS_K_RERANK, m_big, 36 * m_big);
+                DgRegroupIn rin{bk[rbig], m_big, rb};
+                DgRegroupOut rout{bk[rbig], bv[rbig], bpos, m_big, rb, t_idx, t_head, state, prev, out, (unsigned long long *)cnt};
+                BWTS_TRY((device_scan<true, u64>(ctx, m_big, rin, rout, OpMax2(), (u64)0, sp.scan_temp)));
+            }
+        }
+        {
+            SpanGuard g(ctx, BWTS_K_RERANK, a, 18 * a);
+            DgKeepIn kin{state};
+            DgKeepOut kout{state, t_idx, t_head, sp.rank, sets[nxt].idx, sets[nxt].head, a, cnt + 0};
+            BWTS_TRY((device_scan<false, u32>(ctx, a, kin, kout, OpAdd(), 0u, sp.scan_temp)));
+        }
+        BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
+        const u64 a_new = ctx->h_small[SM_COUNTERS + 0];
+        const u64 splits = ctx->h_small[SM_COUNTERS + 2];
+        if (a_new > a) return BWTS_E_INTERNAL;
+        cur = sets[nxt];
+        nxt ^= 1;
+        a = a_new;
+        if (CYCLIC && rounds - 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[rounds - 1] = a;
+        if (a == 0) break;
+        if (CYCLIC && splits == 0) break;               // partition stable under doubling: equal infinite words
+        if (!CYCLIC && h >= n) return BWTS_E_INTERNAL;  // suffixes are distinct; cannot happen
+        if (rounds > 80) return BWTS_E_INTERNAL;
+    }
+    if (need_sa) {
+        SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
+        u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+        sa_from_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.rank, n, SA);
+        HIPC(hipGetLastError());
+    }
+    if (a) {
+        // groups of equal infinite words: their members take the group's slots in list order
+        SpanGuard g(ctx, BWTS_K_EMIT, a, 10 * a);
+        DgRestIn rin{cur.head};
+        DgRestOut rout{cur.idx, cur.head, prev, out, need_sa ? SA : nullptr};
+        BWTS_TRY((device_scan<true, u32>(ctx, a, rin, rout, OpMax(), 0u, sp.scan_temp)));
+    }
+    *rounds_io = rounds;
     return BWTS_OK;
 }
 
@@ -1379,14 +1748,19 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     ActiveList none{nullptr, nullptr, nullptr};
 
     if (a > 0) {
-        if (a > 0xffffffffull) return BWTS_E_RANGE;
-        // aux: two key buffers, one value scratch, two list sets
+        // every position tied at n = 2^32 (a constant or a two-symbol periodic input of exactly 4 GiB): the side buffers of the
+        // later rounds are sized by the tied count and do not fit next to the 36 n bytes of round 0
+        if (a > 0xffffffffull) return BWTS_E_NOMEM;
+        // few tied elements: sparse rank map; many (real text ties most m-grams): the dense rank array
+        const bool sparse = a <= n / 32;
+        static const bool legacy_dense = [] { const char *e = getenv("BWTS_DENSE"); return e && !strcmp(e, "legacy"); }();
+        // aux: two key buffers, one value scratch, two list sets (the group-local dense rounds lay out their own, smaller block)
         char *base = nullptr;
         const size_t e4 = align_up((size_t)a * 4, 256), e8 = align_up((size_t)a * 8, 256);
         const size_t dir_bytes = align_up(((size_t)1 << K0_DIR_LOG2_MAX) * 8 + 8, 256) + align_up(((size_t)1 << K0_DIR_LOG2_MAX) * 4 + 8, 256);
         const size_t e1 = align_up((size_t)a, 256);
         const size_t seg_bytes = e1 + 2 * e8 + 3 * e4;            // flags, compacted keys x2, values x2, slots of the larger groups
-        BWTS_TRY(aux_reserve(ctx, 2 * e8 + 9 * e4 + dir_bytes + seg_bytes, &base));
+        if (sparse || legacy_dense) BWTS_TRY(aux_reserve(ctx, 2 * e8 + 9 * e4 + dir_bytes + seg_bytes, &base));
         u64 *akeys[2] = {(u64 *)base, (u64 *)(base + e8)};
         char *q = base + 2 * e8;
         u32 *scratch = (u32 *)q; q += e4;
@@ -1400,8 +1774,6 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         if (2 * rb > 64) return BWTS_E_RANGE;
         const int round_key_bits = 2 * rb > 1 ? 2 * rb : 1;
         int nxt = 0;
-        // few tied elements: sparse rank map; many (real text ties most m-grams): the dense rank array, built once now
-        const bool sparse = a <= n / 32;
         u32 *tpos = nullptr, *trank = nullptr;
         u64 *dir = nullptr;
         u32 *pdir = nullptr;
@@ -1457,6 +1829,16 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
                 BWTS_TRY(build_ranks(ctx, SA, n, cur, a, sp.rank));
             }
             rank_valid = true;
+            if (!legacy_dense) {
+                // group-local rounds; SA is only rebuilt when someone reads it afterwards (suffix array requested, or the
+                // gather form of the emission)
+                const bool need_sa = !CYCLIC || !sp.carry_out;
+                BWTS_TRY((dense_rounds<CYCLIC>(ctx, d_T, n, al, d_fstart, k, sp, cur, a, SA, need_sa, &rounds)));
+                sp.ties_emitted = CYCLIC && sp.carry_out;
+                *sa_out = SA;
+                *rounds_out = rounds;
+                return BWTS_OK;
+            }
         }
 
         bool seg_skip_next = false;
@@ -2047,7 +2429,7 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 
     // 3. emission: either it rode on the sort (only the tied elements are patched), or a gather
     if (carry) {
-        if (active0) {
+        if (active0 && !sp.ties_emitted) {
             SpanGuard g(ctx, BWTS_K_EMIT, active0, 6 * active0);
             patch_ties_kernel<<<dim3((unsigned)((active0 + 255) / 256)), dim3(256), 0, ctx->stream>>>(sp.tie_slots, active0, SA, P, d_in, n, d_fstart, k, d_out);
         }

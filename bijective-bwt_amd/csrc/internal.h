@@ -51,8 +51,9 @@ struct bwts_ctx {
     // device arena: one allocation, bump-allocated per call, grown between calls
     char  *arena;
     size_t arena_cap, arena_off;
-    char  *aux;
-    size_t aux_cap;
+    char  *aux[2];         // side arenas sized on demand (forward: tied-set buffers; inverse: unreached-element lists, cycle sort)
+    size_t aux_cap[2];
+    size_t unv_hint;       // inverse: unreached elements seen by the previous call (sizes the first collection pass)
 
     // small pinned host block for read-backs, and a device mirror
     u64 *h_small;          // 4096 u64
@@ -161,7 +162,8 @@ size_t inverse_arena_bytes(u64 n);
 int suffix_sort_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u32 **d_sa, u32 **d_rank, u32 *rounds);
 int lyndon_factors_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u32 **d_fstart, u64 *k, u32 *rounds);
 int byte_histogram_device(bwts_ctx *ctx, const u8 *d_T, u64 n, u64 *d_hist256);
-int aux_reserve(bwts_ctx *ctx, size_t bytes, char **base);   // second arena, sized on demand
+int aux_reserve_slot(bwts_ctx *ctx, int slot, size_t bytes, char **base);   // side arenas, sized on demand
+static inline int aux_reserve(bwts_ctx *ctx, size_t bytes, char **base) { return aux_reserve_slot(ctx, 0, bytes, base); }
 
 // ---- generators / utilities (gen.hip) ------------------------------------------------
 int generate_device_impl(bwts_ctx *ctx, int kind, u64 seed, u64 n, u8 *d_out);

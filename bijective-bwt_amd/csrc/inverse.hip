@@ -14,10 +14,8 @@
 #include "device_utils.h"
 #include "scan_templ.h"
 
-#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
-#include <vector>
 
 #define LF_THREADS 256
 #define LF_WAVES   4
@@ -108,16 +106,24 @@ __global__ __launch_bounds__(LF_THREADS) void lf_rank_kernel(const u8 *__restric
 }
 
 // C[c] = first slot of symbol c = tile 0's offset in the scanned [tile][symbol] table; C[256] = n.  The table is 32-bit:
-// a boundary equal to 2^32 (n = 2^32, symbols above the largest one present) reads as a value below its predecessor.
-__global__ void ctab_from_tiles_kernel(const u32 *__restrict__ tile_off, u64 n, u64 *__restrict__ C)
+// a boundary equal to 2^32 (n = 2^32, symbols above the largest one present) reads as a value below its predecessor --
+// unless the predecessor is 0 too, i.e. one symbol holds all 2^32 positions: then every entry reads 0 and B[0] says which
+// symbol that is.
+__global__ void ctab_from_tiles_kernel(const u32 *__restrict__ tile_off, u64 n, const u8 *__restrict__ B, u64 *__restrict__ C)
 {
     if (threadIdx.x != 0) return;
     u64 prev = 0;
+    bool all_zero = true;
     for (int c = 0; c < 256; c++) {
         u64 v = tile_off[c];
+        all_zero = all_zero && v == 0;
         if (v < prev) v += 0x100000000ull;
         C[c] = v;
         prev = v;
+    }
+    if (all_zero && n == 0x100000000ull) {
+        const int b = B[0];
+        for (int c = b + 1; c < 256; c++) C[c] = n;
     }
     C[256] = n;
 }
@@ -170,8 +176,7 @@ __device__ __forceinline__ u32 symbol_of(const u64 *Ctab, u32 y)
 template <int MARK>
 __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, u8 *__restrict__ marks, u32 *__restrict__ idxlog, u64 s, u64 node_cap, int g, u32 slot,
                                                           const u64 *__restrict__ Cg, u8 *__restrict__ seg,
-                                                          u32 *__restrict__ nxt, u32 *__restrict__ seglen,
-                                                          u32 *__restrict__ segmin, u32 *__restrict__ segminoff,
+                                                          uint4 *__restrict__ noderec /* x next node, y segment length, z smallest element, w its offset */,
                                                           unsigned long long *__restrict__ ticket,
                                                           unsigned long long *__restrict__ vcount,
                                                           unsigned long long *__restrict__ overflow,
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                     next_node = s + atomicAdd(vcount, 1ull);
                     if (next_node >= node_cap) { atomicAdd(overflow, 1ull); next_node = node_cap - 1; }
                 }
-                nxt[my] = (u32)next_node; seglen[my] = len; segmin[my] = mn; segminoff[my] = mnoff;
+                noderec[my] = make_uint4((u32)next_node, len, mn, mnoff);
                 if (!at_splitter) { my = next_node; len = 0; mn = x; mnoff = 0; sb0 = sb1 = sb2 = sb3 = 0; }
             } else if (x < mn) { mn = x; mnoff = len; }
         }
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
 // node that straddles the wrap point, and a ragged tail, go byte by byte.
 struct __attribute__((packed, aligned(1))) Unaligned16 { u32 w[4]; };
 __global__ __launch_bounds__(256) void place_segments_kernel(const u8 *__restrict__ seg, u64 nodes, u32 slot, int tpn_log2,
-                                                             const u32 *__restrict__ seglen, const u32 *__restrict__ opos,
+                                                             const uint4 *__restrict__ noderec, const u32 *__restrict__ opos,
                                                              const u32 *__restrict__ wrap_at, const u32 *__restrict__ cyc_len,
                                                              u8 *__restrict__ out)
 {
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256) void place_segments_kernel(const u8 *__restric
     const u64 v = gid >> tpn_log2;
     if (v >= nodes) return;
     const u32 sub = (u32)(gid & ((1ull << tpn_log2) - 1ull)), tpn = 1u << tpn_log2;
-    const u32 len = seglen[v], o = opos[v], wr = wrap_at[v], L = cyc_len[v];
+    const u32 len = noderec[v].y, o = opos[v], wr = wrap_at[v], L = cyc_len[v];
     const u8 *src = seg + v * slot;
     for (u32 c = sub * 16; c < len; c += tpn * 16) {
         if (c + 16 <= len && (c + 16 <= wr || c >= wr)) {
@@ -445,49 +450,106 @@ __global__ __launch_bounds__(1024) void unvisited_from_buckets_kernel(const u32 
         atomicOr(&bm[o >> 5], 1u << (o & 31u));
     }
     __syncthreads();
+    // natural inputs leave a few dozen zero bits; constant or sorted inputs leave nearly all of them: the room in the
+    // list is reserved once per wave and step, not once per element
     const u64 lo = (u64)b << IDX_RANGE_LOG2;
-    for (u32 w = threadIdx.x; w < (1u << IDX_RANGE_LOG2) / 32; w += 1024) {
+    for (u32 w0 = 0; w0 < (1u << IDX_RANGE_LOG2) / 32; w0 += 1024) {
+        const u32 w = w0 + threadIdx.x;
         u32 zeros = ~bm[w];
+        const u64 xbase = lo + (u64)w * 32;
+        if (xbase >= n) zeros = 0;
+        else if (n - xbase < 32) zeros &= (1u << (u32)(n - xbase)) - 1u;
+        const u32 mine = (u32)__popc(zeros);
+        const u32 inc = wave_scan_inclusive(mine, OpAdd());
+        const u32 tot = shfl_t(inc, 63);
+        if (tot == 0) continue;
+        unsigned long long base = 0;
+        if (lane_id() == 63) base = atomicAdd(count, (unsigned long long)tot);
+        base = shfl_t((u64)base, 63);
+        u64 at = base + (inc - mine);
         while (zeros) {
             const u32 bit = (u32)__ffs((int)zeros) - 1u;
             zeros &= zeros - 1u;
-            const u64 x = lo + (u64)w * 32 + bit;
-            if (x < n) {
-                const unsigned long long at = atomicAdd(count, 1ull);      // rare: a few thousand on natural inputs
-                if (at < cap) { uidx[at] = (u32)x; ulf[at] = LF[x]; }
-            }
+            const u64 x = xbase + bit;
+            if (at < cap) { uidx[at] = (u32)x; ulf[at] = LF[x]; }
+            at++;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void scatter_bytes_kernel(const u32 *__restrict__ pos, const u8 *__restrict__ sym, u64 m, u8 *__restrict__ out)
-{
-    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < m) out[pos[i]] = sym[i];
-}
-
 // ------------------------------------------------------------------------------------
-// reduced-list ranking (splitter nodes) by pointer jumping
+// reduced-list ranking (splitter nodes): two levels, linear work
 // ------------------------------------------------------------------------------------
-// node v: nxt[v] next splitter on its cycle, len[v] elements in its segment, mn[v] smallest element of the
-// segment and off[v] its distance from the splitter.  Wanted per node: its cycle's leader (smallest node
-// id), length, smallest element, and the node's distance from that smallest element along LF.
+// node v (noderec[v]): x = next node on its cycle, y = elements in its segment, z = smallest element of the segment,
+// w = that element's distance from the node's first element.  Wanted per node: where its segment goes in the text, i.e.
+// its cycle's end position, the cycle's length, and the node's distance from the cycle's smallest element.
+//
+// Pointer jumping over all nodes is O(s log s) work in 2 log s launches; that is what kept the splitter spacing G large.
+// Instead every L2_H-th node is a level-2 splitter: a lane walks the node list from its level-2 splitter to the next one
+// (lr2_walk_kernel: sums, minima, visit marks), nodes no such walk reached -- node cycles without a level-2 splitter --
+// join the level-2 list as they are (lr2_collect / lr2_fill), the level-2 list (~ s / L2_H entries) is ranked by pointer
+// jumping, and a second walk hands the positions down to the nodes (lr2_distribute_kernel).
+#define L2_H 32
 #define LR_NIL 0xffffffffu
 
-// A round of pointer jumping reads the record of the node it hops to: the fields travel together (16 and 8 bytes), so
-// a round costs one random line fill per node instead of three (two).
-//   LrMin  x = smallest node id seen (-> leader), y = smallest element seen, z = hop target
+__global__ __launch_bounds__(256) void lr2_walk_kernel(const uint4 *__restrict__ noderec, u64 s2, u8 *__restrict__ visited, uint4 *__restrict__ rec2)
+{
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w >= s2) return;
+    u32 v = (u32)(w * L2_H), acc = 0, mn = 0, mnoff = 0;
+    bool first = true;
+    do {
+        const uint4 r = noderec[v];
+        visited[v] = 1;
+        if (first || r.z < mn) { mn = r.z; mnoff = acc + r.w; first = false; }
+        acc += r.y;
+        v = r.x;
+    } while (v % L2_H != 0);
+    rec2[w] = make_uint4(v / L2_H, acc, mn, mnoff);
+}
+
+// nodes on cycles without a level-2 splitter: each becomes a level-2 entry of its own (id = s2 + position in U)
+__global__ __launch_bounds__(256) void lr2_collect_kernel(const u8 *__restrict__ visited, u64 s_all, u64 s2, u32 *__restrict__ U,
+                                                          u32 *__restrict__ id2of, unsigned long long *__restrict__ count)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool un = v < s_all && !visited[v];
+    const u64 m = __ballot(un);
+    if (m == 0) return;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    unsigned long long b = 0;
+    if (lane_id() == leader) b = atomicAdd(count, (unsigned long long)__popcll(m));
+    b = shfl_t((u64)b, leader);
+    if (un) {
+        const u64 at = b + (u64)__popcll(m & lanemask_lt());
+        U[at] = (u32)v;
+        id2of[v] = (u32)(s2 + at);
+    }
+}
+__global__ __launch_bounds__(256) void lr2_fill_kernel(const u32 *__restrict__ U, u64 nu2, u64 s2, const uint4 *__restrict__ noderec,
+                                                       const u32 *__restrict__ id2of, uint4 *__restrict__ rec2)
+{
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= nu2) return;
+    const uint4 r = noderec[U[j]];
+    rec2[s2 + j] = make_uint4(id2of[r.x], r.y, r.z, r.w);       // the successor of an unreached node is unreached too
+}
+
+// ---- pointer jumping over the level-2 list -------------------------------------------------------------------------
+// A round reads the record of the entry it hops to: the fields travel together (16 and 8 bytes), so a round costs one
+// random line fill per entry instead of three (two).
+//   LrMin  x = smallest entry id seen (-> leader), y = smallest element seen, z = hop target
 //   LrSum  x = segment lengths summed up to the cut, y = hop target (LR_NIL at the cut)
 typedef uint4 LrMin;
 typedef uint2 LrSum;
 
-__global__ __launch_bounds__(256) void lr_init_kernel(u64 s, const u32 *__restrict__ nxt, const u32 *__restrict__ mn, LrMin *__restrict__ rec)
+__global__ __launch_bounds__(256) void lr_init_kernel(u64 s, const uint4 *__restrict__ rec2, LrMin *__restrict__ rec)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (v < s) rec[v] = make_uint4((u32)v, mn[v], nxt[v], 0u);
+    if (v < s) { const uint4 r = rec2[v]; rec[v] = make_uint4((u32)v, r.z, r.x, 0u); }
 }
 
-// after r rounds a node has folded in the 2^r nodes that follow it
+// after r rounds an entry has folded in the 2^r entries that follow it
 __global__ __launch_bounds__(256) void lr_jump_min_kernel(u64 s, const LrMin *__restrict__ in, LrMin *__restrict__ out)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -497,12 +559,11 @@ __global__ __launch_bounds__(256) void lr_jump_min_kernel(u64 s, const LrMin *__
     out[v] = make_uint4(a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, b.z, 0u);
 }
 
-// cut every cycle in front of its leader, then suffix sums of the segment lengths
-__global__ __launch_bounds__(256) void lr_cut_kernel(u64 s, const u32 *__restrict__ nxt, const u32 *__restrict__ len,
-                                                     const LrMin *__restrict__ rec, LrSum *__restrict__ sh)
+// cut every cycle in front of its leader, then suffix sums of the lengths
+__global__ __launch_bounds__(256) void lr_cut_kernel(u64 s, const uint4 *__restrict__ rec2, const LrMin *__restrict__ rec, LrSum *__restrict__ sh)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (v < s) { const u32 nx = nxt[v]; sh[v] = make_uint2(len[v], nx == rec[v].x ? LR_NIL : nx); }
+    if (v < s) { const uint4 r = rec2[v]; sh[v] = make_uint2(r.y, r.x == rec[v].x ? LR_NIL : r.x); }
 }
 
 __global__ __launch_bounds__(256) void lr_jump_sum_kernel(u64 s, const LrSum *__restrict__ in, LrSum *__restrict__ out)
@@ -514,12 +575,14 @@ __global__ __launch_bounds__(256) void lr_jump_sum_kernel(u64 s, const LrSum *__
     else { const LrSum b = in[a.y]; out[v] = make_uint2(a.x + b.x, b.y); }
 }
 
+// One record per LF cycle, for the ordering by smallest element (unbwts.c:62-77).  leader = level-2 leader entry, or
+// LR_NIL for a cycle without a splitter (resolved by tiny_cycle_scan_kernel).
 struct CycleRec { u32 leader; u32 minelem; u32 len; u32 pad; };
 
-// dist[v] = elements between the leader's splitter and v's splitter; the node whose segment holds the
-// cycle's smallest element publishes that element's distance; leaders append a cycle record
+// dist[v] = elements between the leader's first element and v's; the entry whose stretch holds the cycle's smallest
+// element publishes that element's distance; leaders append a cycle record
 __global__ __launch_bounds__(256) void lr_finish_kernel(u64 s, const LrMin *__restrict__ rec, const LrSum *__restrict__ sh,
-                                                        const u32 *__restrict__ mn, const u32 *__restrict__ off, u32 *__restrict__ dist,
+                                                        const uint4 *__restrict__ rec2, u32 *__restrict__ dist,
                                                         u32 *__restrict__ min_dist /* by leader */, CycleRec *__restrict__ recs,
                                                         unsigned long long *__restrict__ nrec)
 {
@@ -530,7 +593,8 @@ __global__ __launch_bounds__(256) void lr_finish_kernel(u64 s, const LrMin *__re
     const u32 L = sh[l].x;
     const u32 d = L - sh[v].x;
     dist[v] = d;
-    if (mn[v] == r.y) min_dist[l] = d + off[v];
+    const uint4 r2 = rec2[v];
+    if (r2.z == r.y) min_dist[l] = d + r2.w;
     if (l == (u32)v) {
         const unsigned long long at = atomicAdd(nrec, 1ull);
         CycleRec c; c.leader = l; c.minelem = r.y; c.len = L; c.pad = 0;
@@ -538,27 +602,123 @@ __global__ __launch_bounds__(256) void lr_finish_kernel(u64 s, const LrMin *__re
     }
 }
 
-__global__ __launch_bounds__(256) void lr_place_kernel(u64 s, const LrMin *__restrict__ rec, const LrSum *__restrict__ sh,
-                                                       const u32 *__restrict__ dist, const u32 *__restrict__ min_dist,
-                                                       const u32 *__restrict__ end_by_leader, u32 *__restrict__ opos,
-                                                       u32 *__restrict__ wrap_at, u32 *__restrict__ cyc_len)
+// level-2 entry -> distance of its first element from the cycle's smallest element, the cycle's length and end
+__global__ __launch_bounds__(256) void lr_place2_kernel(u64 s, const LrMin *__restrict__ rec, const LrSum *__restrict__ sh,
+                                                        const u32 *__restrict__ dist, const u32 *__restrict__ min_dist,
+                                                        const u32 *__restrict__ end_by_leader, uint4 *__restrict__ place2)
 {
     const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
     if (v >= s) return;
     const u32 l = rec[v].x;
-    const u32 L = sh[l].x;
+    const u32 L = sh[l].x;                       // a cycle of 2^32 elements reads as 0: the arithmetic below is mod 2^32
     const u32 dm = min_dist[l];
     const u32 d = dist[v];
-    const u32 t = d >= dm ? d - dm : d + L - dm;     // distance of v's splitter from the cycle's smallest element
-    opos[v] = end_by_leader[l] - t;
-    wrap_at[v] = L - t;
-    cyc_len[v] = L;
+    const u32 t = d >= dm ? d - dm : d + L - dm;
+    place2[v] = make_uint4(t, L, end_by_leader[l], 0u);
 }
 
-__global__ __launch_bounds__(256) void scatter_u32_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ val, u64 m, u32 *__restrict__ out)
+// hands the positions down to the nodes: opos = text position of the node's first symbol, wrap_at = symbols until the
+// walk passes the cycle's smallest element (the text position wraps to the cycle's end there), cyc_len
+__global__ __launch_bounds__(256) void lr2_distribute_kernel(const uint4 *__restrict__ noderec, u64 s2, u64 s2all, const u32 *__restrict__ U,
+                                                             const uint4 *__restrict__ place2, u32 *__restrict__ opos,
+                                                             u32 *__restrict__ wrap_at, u32 *__restrict__ cyc_len)
+{
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w >= s2all) return;
+    const uint4 pl = place2[w];
+    const u64 L = pl.y ? (u64)pl.y : 0x100000000ull;
+    u64 t = pl.x;
+    if (w >= s2) {
+        const u32 v = U[w - s2];
+        opos[v] = pl.z - (u32)t; wrap_at[v] = (u32)(L - t); cyc_len[v] = (u32)L;
+        return;
+    }
+    u32 v = (u32)(w * L2_H);
+    do {
+        const uint4 r = noderec[v];
+        opos[v] = pl.z - (u32)t; wrap_at[v] = (u32)(L - t); cyc_len[v] = (u32)L;
+        t += r.y;
+        if (t >= L) t -= L;
+        v = r.x;
+    } while (v % L2_H != 0);
+}
+
+// ------------------------------------------------------------------------------------
+// cycles without a splitter (elements no walk reached)
+// ------------------------------------------------------------------------------------
+// Natural inputs leave a few dozen such elements (tiny Lyndon factors); a constant or sorted input leaves nearly all n
+// (LF is close to the identity).  Everything here is sized by their number and stays on the device.
+// An unreached element follows its own cycle until it meets a smaller element (not the cycle's minimum: done) or
+// returns to itself (it is the minimum: it appends the cycle's record).  `cap` bounds the steps of one lane.
+__global__ __launch_bounds__(256) void tiny_cycle_scan_kernel(const u32 *__restrict__ uidx, const u32 *__restrict__ ulf, u64 nu,
+                                                              const u32 *__restrict__ LF, u32 cap, CycleRec *__restrict__ recs,
+                                                              unsigned long long *__restrict__ count, unsigned long long *__restrict__ overflow)
+{
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    bool ismin = false;
+    u32 x = 0, len = 1;
+    if (q < nu) {
+        x = uidx[q];
+        u32 y = ulf[q];
+        ismin = true;
+        while (y != x) {
+            if (y < x) { ismin = false; break; }
+            y = LF[y];
+            if (++len > cap) { atomicAdd(overflow, 1ull); ismin = false; break; }
+        }
+    }
+    const u64 m = __ballot(ismin);
+    if (m == 0) return;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    unsigned long long b = 0;
+    if (lane_id() == leader) b = atomicAdd(count, (unsigned long long)__popcll(m));
+    b = shfl_t((u64)b, leader);
+    if (ismin) {
+        CycleRec c; c.leader = LR_NIL; c.minelem = x; c.len = len; c.pad = 0;
+        recs[b + (u64)__popcll(m & lanemask_lt())] = c;
+    }
+}
+
+// ---- cycle order: by smallest element, the cycle holding index 0 ends the text (unbwts.c:62-77) ------------------------
+__global__ __launch_bounds__(256) void cycle_keys_kernel(const CycleRec *__restrict__ recs, u64 m, u64 *__restrict__ keys, u32 *__restrict__ vals)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < m) out[idx[i]] = val[i];
+    if (i < m) { keys[i] = recs[i].minelem; vals[i] = (u32)i; }
+}
+struct CycleLenIn {
+    const CycleRec *recs; const u32 *order;
+    __device__ __forceinline__ u32 operator()(u64 j) const { return recs[order[j]].len; }
+};
+struct CycleEndOut {
+    const CycleRec *recs; const u32 *order; u64 m; u32 last; u32 *end_by_leader; u32 *end_of_rec; u64 *total;
+    __device__ __forceinline__ void operator()(u64 j, u32 used) const
+    {
+        const u32 i = order[j];
+        const CycleRec c = recs[i];
+        const u32 end = last - used;                    // n - 1 - (elements of the cycles ordered before this one)
+        if (c.leader != LR_NIL) end_by_leader[c.leader] = end;
+        end_of_rec[i] = end;
+        if (j + 1 == m) *total = (u64)used + c.len;     // == n (mod 2^32 for n = 2^32)
+    }
+};
+
+// out[end - t] = B[LF^t(min)] for a cycle without a splitter: unbwts.c:73-82, one lane per cycle
+__global__ __launch_bounds__(256) void tiny_place_kernel(const CycleRec *__restrict__ recs, u64 m, const u32 *__restrict__ end_of_rec,
+                                                         const u32 *__restrict__ LF, const u64 *__restrict__ Cg, u8 *__restrict__ out)
+{
+    __shared__ u64 Ctab[257];
+    for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
+    __syncthreads();
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const CycleRec c = recs[i];
+    if (c.leader != LR_NIL) return;
+    u32 x = c.minelem, pos = end_of_rec[i];
+    for (u32 t = 0; t < c.len; t++) {
+        const u32 y = LF[x];
+        out[pos--] = (u8)symbol_of(Ctab, y);
+        x = y;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -567,26 +727,33 @@ __global__ __launch_bounds__(256) void scatter_u32_kernel(const u32 *__restrict_
 static int splitter_log2(u64 n)
 {
     int bl = 0; for (u64 x = n; x; x >>= 1) bl++;
-    int g = bl - 21;
+    int g = bl - 24;
     if (g < 4) g = 4;
-    if (g > 9) g = 9;
+    if (g > 8) g = 8;
     const char *env = getenv("BWTS_SPLIT_LOG2");
     if (env) { int v = atoi(env); if (v >= 0 && v <= 20) g = v; }
     return g;
 }
 
-#define UNV_CAP (1ull << 20)     // unvisited elements collected by the single sweep
+#define UNV_CAP0 (1ull << 20)     // room for unreached elements before their number is known
+
+static size_t inverse_node_bytes(u64 node_cap, u32 slot)
+{
+    const u64 l2cap = node_cap / L2_H + 2 + node_cap;        // worst case: no node is reached by a level-2 walk
+    return align_up(node_cap * 16, 256) + 5 * align_up(node_cap * 4, 256) + align_up(node_cap, 256) + align_up(node_cap * slot, 256) +
+           4 * align_up(l2cap * 16, 256) + 2 * align_up(l2cap * 8, 256) + 3 * align_up(l2cap * 4, 256) + align_up(l2cap * sizeof(CycleRec), 256);
+}
 
 size_t inverse_arena_bytes(u64 n)
 {
     const u64 s = (n >> 4) + 2;   // upper bound on splitters (g >= 4)
-    return align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 24 * align_up(s * 4, 256) + (1 << 16);
+    return align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + inverse_node_bytes(s + s / 8 + 1024, 64) + (1 << 16);
 }
 
 static int grid1(u64 m) { return (int)((m + 255) / 256); }
 
-// One attempt with splitter spacing 2^g.  *retry is set when more elements sit in splitter-free cycles than
-// the sweep collects; the caller then repeats with g = 0 (every element a splitter: plain pointer jumping).
+// One attempt with splitter spacing 2^g.  *retry is set when the node pool overflows or a cycle without a splitter is
+// longer than one lane may follow (adversarial LF); the caller then repeats with g = 0 (every element a splitter).
 static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int g, int mark, bool *retry, bool *ambiguous)
 {
     *retry = false;
@@ -598,25 +765,29 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     // a segment longer than `slot` steps is cut into virtual nodes; room for s/8 of them (natural data needs ~2 %)
     const u32 slot = (u32)(4 * G < 16 ? 16 : 4 * G);
     const u64 node_cap = g == 0 ? s : s + s / 8 + 1024;
-    const size_t s4 = align_up(node_cap * 4, 256);
+    const u64 l2cap = node_cap / L2_H + 2 + node_cap;
     u64 walker_cap = 524288;
     if (const char *e = getenv("BWTS_WALKERS")) { const long v = atol(e); if (v >= 256 && v <= (1 << 22)) walker_cap = (u64)v; }
     const u64 walkers = s < walker_cap ? s : walker_cap;
     const unsigned wblocks = (unsigned)((walkers + 255) / 256);
     const u64 log_chunks = n / (IDX_CHUNK - 64) + (u64)wblocks * 4 + 2;     // a closed chunk wastes < 64 entries; every wave may leave one open
-    BWTS_TRY(arena_reserve(ctx, align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 24 * s4 +
-                                    align_up(node_cap * sizeof(CycleRec), 256) + align_up(node_cap * slot, 256) + align_up(n, 256) +
+    BWTS_TRY(arena_reserve(ctx, align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + inverse_node_bytes(node_cap, slot) +
+                                    align_up(n, 256) +
                                     (mark == MARK_LOG ? align_up(log_chunks * IDX_CHUNK * 4, 256) + align_up(log_chunks * 4, 256) + align_up(n * 4 + (4ull << IDX_RANGE_LOG2), 256) + (1 << 20) : 0) +
                                     (1 << 16)));
     u32 *LF = arena_array<u32>(ctx, n);
     u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
     void *scan_temp = arena_alloc(ctx, scan_temp_bytes(n));
-    u32 *node[12];
-    for (int i = 0; i < 12; i++) node[i] = arena_array<u32>(ctx, node_cap);
-    LrMin *lrmin[2] = {arena_array<LrMin>(ctx, node_cap), arena_array<LrMin>(ctx, node_cap)};
-    LrSum *lrsum[2] = {arena_array<LrSum>(ctx, node_cap), arena_array<LrSum>(ctx, node_cap)};
-    CycleRec *d_recs = (CycleRec *)arena_alloc(ctx, node_cap * sizeof(CycleRec));
+    uint4 *noderec = arena_array<uint4>(ctx, node_cap);
+    u32 *d_opos = arena_array<u32>(ctx, node_cap), *d_wrap = arena_array<u32>(ctx, node_cap), *d_clen = arena_array<u32>(ctx, node_cap);
+    u32 *id2of = arena_array<u32>(ctx, node_cap), *U = arena_array<u32>(ctx, node_cap);
+    u8 *visited2 = arena_array<u8>(ctx, node_cap);
     u8 *seg = arena_array<u8>(ctx, node_cap * slot);
+    uint4 *rec2 = arena_array<uint4>(ctx, l2cap), *place2 = arena_array<uint4>(ctx, l2cap);
+    LrMin *lrmin[2] = {arena_array<LrMin>(ctx, l2cap), arena_array<LrMin>(ctx, l2cap)};
+    LrSum *lrsum[2] = {arena_array<LrSum>(ctx, l2cap), arena_array<LrSum>(ctx, l2cap)};
+    u32 *dist = arena_array<u32>(ctx, l2cap), *min_dist = arena_array<u32>(ctx, l2cap), *end_by_leader = arena_array<u32>(ctx, l2cap);
+    CycleRec *d_recs2 = (CycleRec *)arena_alloc(ctx, l2cap * sizeof(CycleRec));      // cycles of the reduced list (copied next to the others later)
     const bool bytemark = mark == MARK_BYTEMAP;
     u8 *marks = bytemark ? arena_array<u8>(ctx, n) : nullptr;
     const u32 nbuckets = (u32)((n + (1ull << IDX_RANGE_LOG2) - 1) >> IDX_RANGE_LOG2);
@@ -626,17 +797,13 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     u32 *bucket_fill = mark == MARK_LOG ? arena_array<u32>(ctx, (u64)IDX_MAX_BUCKETS * IDX_FILL_STRIDE) : nullptr;
     u32 *bucket_seen = mark == MARK_LOG ? arena_array<u32>(ctx, 2 * IDX_MAX_BUCKETS) : nullptr;   // counts, then deficit flags
     u32 *deficient = bucket_seen ? bucket_seen + IDX_MAX_BUCKETS : nullptr;
-    if (!LF || !tile_hist || !scan_temp || !node[11] || !lrmin[1] || !lrsum[1] || !d_recs || !seg || (bytemark && !marks) ||
+    if (!LF || !tile_hist || !scan_temp || !noderec || !d_opos || !d_wrap || !d_clen || !id2of || !U || !visited2 || !seg || !rec2 || !place2 ||
+        !lrmin[0] || !lrmin[1] || !lrsum[0] || !lrsum[1] || !dist || !min_dist || !end_by_leader || !d_recs2 || (bytemark && !marks) ||
         (mark == MARK_LOG && (!idxlog || !chunk_fill || !bucket_data || !bucket_fill || !bucket_seen)))
         return BWTS_E_NOMEM;
     if (bytemark) HIPC(hipMemsetAsync(marks, 0, n, ctx->stream));
-    u32 *nxt = node[0], *seglen = node[1], *segmin = node[2], *segoff = node[3];
-    u32 *d_opos = node[4], *d_wrap = node[5], *d_clen = node[6];
-    u32 *dist = node[7], *min_dist = node[8], *end_by_leader = node[9];
-    u32 *tmp_idx = node[10], *tmp_val = node[11];
 
-    u64 *hC = ctx->h_small + 1024;          // symbol boundaries C[0..256] (unbwts.c:38-43); filled below
-    u64 *dC = ctx->d_small + 1024;
+    u64 *dC = ctx->d_small + 1024;          // symbol boundaries C[0..256] (unbwts.c:38-43); filled below
 
     // stable LF map (unbwts.c:50-52)
     {
@@ -644,12 +811,14 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         lf_hist_kernel<<<dim3((unsigned)tiles), dim3(LF_THREADS), 0, ctx->stream>>>(d_in, n, tile_hist);
         BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, scan_temp));
         // the scanned table's first row is C itself: no separate histogram sweep, no host round trip before the walk
-        ctab_from_tiles_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(tile_hist, n, dC);
+        ctab_from_tiles_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(tile_hist, n, d_in, dC);
         lf_rank_kernel<<<dim3((unsigned)tiles), dim3(LF_THREADS), 0, ctx->stream>>>(d_in, n, tile_hist, LF);
         HIPC(hipGetLastError());
     }
 
     // the walk: marks, segment symbols, reduced list
+    // counters: [0] ticket, [1] unreached elements, [2] cycles of the reduced list, [3] virtual nodes, [4] overflow, [5] log chunks,
+    //           [6] unreached nodes, [7] cycles without a splitter, [13] sum of all cycle lengths ([8..12]: WALK_PROFILE stamps)
     unsigned long long *ticket = (unsigned long long *)(ctx->d_small + SMI_COUNTERS);
     HIPC(hipMemsetAsync(ticket, 0, 16 * sizeof(u64), ctx->stream));
 #ifdef WALK_PROFILE
@@ -663,18 +832,17 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 6 * n);
         if (mark == MARK_BYTEMAP)
-            walk_record_kernel<MARK_BYTEMAP><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, nxt, seglen,
-                                                                                          segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
+            walk_record_kernel<MARK_BYTEMAP><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
+                                                                                          ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         else if (mark == MARK_SENTINEL)
-            walk_record_kernel<MARK_SENTINEL><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, nxt, seglen,
-                                                                                           segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
+            walk_record_kernel<MARK_SENTINEL><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
+                                                                                           ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         else
-            walk_record_kernel<MARK_LOG><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, nxt, seglen,
-                                                                                      segmin, segoff, ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
+            walk_record_kernel<MARK_LOG><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
+                                                                                      ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         HIPC(hipGetLastError());
     }
     // virtual nodes join the reduced list: its size is only known now
-    BWTS_TRY(read_small(ctx, 1024, 257));      // C for the host-side steps below
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
 #ifdef WALK_PROFILE
     {
@@ -685,122 +853,127 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
 #endif
     if (ctx->h_small[SMI_COUNTERS + 4]) { *retry = true; return BWTS_OK; }   // node pool exhausted (adversarial LF): plain pointer jumping
     const u64 s_all = s + ctx->h_small[SMI_COUNTERS + 3];
+    const u64 s2 = (s_all + L2_H - 1) / L2_H;
 
-    // elements in splitter-free cycles
-    char *ub = nullptr;
-    BWTS_TRY(aux_reserve(ctx, 2 * align_up(UNV_CAP * 4, 256) + align_up(UNV_CAP, 256), &ub));
-    u32 *uidx = (u32 *)ub, *ulf = (u32 *)(ub + align_up(UNV_CAP * 4, 256));
-    {
-        SpanGuard sg(ctx, BWTS_K_OTHER, n, 4 * n);
+    // elements in cycles without a splitter: collected into lists sized by their number (a second pass if the first room is too small)
+    size_t ucap = ctx->unv_hint > UNV_CAP0 ? ctx->unv_hint : UNV_CAP0;
+    if (ucap > n) ucap = (size_t)n;
+    u32 *uidx = nullptr, *ulf = nullptr, *end_of_rec = nullptr;
+    CycleRec *recs = nullptr;
+    auto lay_out_lists = [&](size_t cap) -> int {
+        // uidx, ulf: cap entries; cycle records and their ends: (cycles of the reduced list <= l2cap) + cap
+        char *ub = nullptr;
+        const size_t e4 = align_up(cap * 4, 256), r16 = align_up((l2cap + cap) * sizeof(CycleRec), 256), r4 = align_up((l2cap + cap) * 4, 256);
+        BWTS_TRY(aux_reserve_slot(ctx, 0, 2 * e4 + r16 + r4, &ub));
+        uidx = (u32 *)ub; ulf = (u32 *)(ub + e4);
+        recs = (CycleRec *)(ub + 2 * e4);
+        end_of_rec = (u32 *)(ub + 2 * e4 + r16);
+        return BWTS_OK;
+    };
+    BWTS_TRY(lay_out_lists(ucap));
+    auto collect_unreached = [&](bool first_time) -> int {
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
         if (mark == MARK_LOG) {
-            HIPC(hipMemsetAsync(bucket_fill, 0, (size_t)nbuckets * IDX_FILL_STRIDE * sizeof(u32), ctx->stream));
             const int bm_bytes = (int)((1u << IDX_RANGE_LOG2) / 8);
-            BWTS_TRY(ensure_dyn_lds(ctx, (const void *)unvisited_from_buckets_kernel, (size_t)bm_bytes));
-            BWTS_TRY(ensure_dyn_lds(ctx, (const void *)bucket_indices_kernel, bucket_indices_lds_bytes(IDX_MAX_BUCKETS)));
-            bucket_deficit_kernel<<<dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream>>>(bucket_seen, nbuckets, n, deficient);
-            bucket_indices_kernel<<<dim3((unsigned)log_chunks), dim3(IDX_THREADS), bucket_indices_lds_bytes(nbuckets), ctx->stream>>>(
-                idxlog, chunk_fill, nbuckets, deficient, bucket_fill, bucket_data);
-            unvisited_from_buckets_kernel<<<dim3(nbuckets), dim3(1024), bm_bytes, ctx->stream>>>(deficient, bucket_fill, bucket_data, LF, n, uidx, ulf, UNV_CAP,
+            if (first_time) {
+                HIPC(hipMemsetAsync(bucket_fill, 0, (size_t)nbuckets * IDX_FILL_STRIDE * sizeof(u32), ctx->stream));
+                BWTS_TRY(ensure_dyn_lds(ctx, (const void *)unvisited_from_buckets_kernel, (size_t)bm_bytes));
+                BWTS_TRY(ensure_dyn_lds(ctx, (const void *)bucket_indices_kernel, bucket_indices_lds_bytes(IDX_MAX_BUCKETS)));
+                bucket_deficit_kernel<<<dim3((nbuckets + 255) / 256), dim3(256), 0, ctx->stream>>>(bucket_seen, nbuckets, n, deficient);
+                bucket_indices_kernel<<<dim3((unsigned)log_chunks), dim3(IDX_THREADS), bucket_indices_lds_bytes(nbuckets), ctx->stream>>>(
+                    idxlog, chunk_fill, nbuckets, deficient, bucket_fill, bucket_data);
+            }
+            unvisited_from_buckets_kernel<<<dim3(nbuckets), dim3(1024), bm_bytes, ctx->stream>>>(deficient, bucket_fill, bucket_data, LF, n, uidx, ulf, ucap,
                                                                                                 ticket + 1);
         } else if (mark == MARK_BYTEMAP)
-            collect_unvisited_kernel<MARK_BYTEMAP><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, UNV_CAP, ticket + 1);
+            collect_unvisited_kernel<MARK_BYTEMAP><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, ucap, ticket + 1);
         else
-            collect_unvisited_kernel<MARK_SENTINEL><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, UNV_CAP, ticket + 1);
+            collect_unvisited_kernel<MARK_SENTINEL><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, ucap, ticket + 1);
+        HIPC(hipGetLastError());
+        return BWTS_OK;
+    };
+    {
+        SpanGuard sg(ctx, BWTS_K_OTHER, n, 4 * n);
+        BWTS_TRY(collect_unreached(true));
+    }
+    // level-2 walk over the node list, and the nodes it does not reach
+    {
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, s_all, 32 * s_all);
+        HIPC(hipMemsetAsync(visited2, 0, s_all, ctx->stream));
+        lr2_walk_kernel<<<dim3(grid1(s2)), dim3(256), 0, ctx->stream>>>(noderec, s2, visited2, rec2);
+        lr2_collect_kernel<<<dim3(grid1(s_all)), dim3(256), 0, ctx->stream>>>(visited2, s_all, s2, U, id2of, ticket + 6);
         HIPC(hipGetLastError());
     }
+    BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
+    const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
+    const u64 nu2 = ctx->h_small[SMI_COUNTERS + 6];
+    ctx->tm.unvisited = nu;
+    if (nu > n || nu2 > s_all) return BWTS_E_INTERNAL;
+    ctx->unv_hint = (size_t)nu;
+    if (nu > ucap) {
+        ucap = (size_t)nu;
+        BWTS_TRY(lay_out_lists(ucap));
+        HIPC(hipMemsetAsync(ticket + 1, 0, sizeof(u64), ctx->stream));
+        SpanGuard sg(ctx, BWTS_K_OTHER, n, 4 * n);
+        BWTS_TRY(collect_unreached(false));
+    }
+    const u64 s2all = s2 + nu2;
 
-    // reduced-list ranking on the device
-    const int R = [&] { int b = 0; for (u64 x = s_all; x; x >>= 1) b++; return b; }();   // 2^R > s >= any cycle's node count
+    // level-2 list ranking by pointer jumping; cycle records of the reduced list; cycles without a splitter
+    const int R = [&] { int b = 0; for (u64 x = s2all; x; x >>= 1) b++; return b; }();   // 2^R > s2all >= any cycle's entry count
     int cur = 0, sc = 0;
     {
-        SpanGuard sg(ctx, BWTS_K_LISTRANK, s_all, 0);
-        const int gb = grid1(s_all);
-        lr_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nxt, segmin, lrmin[0]);
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, s2all, 0);
+        const int gb = grid1(s2all);
+        if (nu2) lr2_fill_kernel<<<dim3(grid1(nu2)), dim3(256), 0, ctx->stream>>>(U, nu2, s2, noderec, id2of, rec2);
+        lr_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s2all, rec2, lrmin[0]);
         for (int r = 0; r < R; r++, cur ^= 1)
-            lr_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, lrmin[cur], lrmin[cur ^ 1]);
-        lr_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nxt, seglen, lrmin[cur], lrsum[0]);
+            lr_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s2all, lrmin[cur], lrmin[cur ^ 1]);
+        lr_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s2all, rec2, lrmin[cur], lrsum[0]);
         for (int r = 0; r < R; r++, sc ^= 1)
-            lr_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, lrsum[sc], lrsum[sc ^ 1]);
-        lr_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, lrmin[cur], lrsum[sc], segmin, segoff, dist, min_dist, d_recs, ticket + 2);
+            lr_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s2all, lrsum[sc], lrsum[sc ^ 1]);
+        lr_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s2all, lrmin[cur], lrsum[sc], rec2, dist, min_dist, d_recs2, ticket + 2);
         HIPC(hipGetLastError());
     }
-    BWTS_TRY(read_small(ctx, SMI_COUNTERS, 4));
-    const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
+    if (nu) {
+        SpanGuard sg(ctx, BWTS_K_OTHER, nu, 8 * nu);
+        // one lane follows at most `cap` elements: bounds the work of an adversarial LF (many long cycles that dodge every splitter)
+        u64 cap = (1ull << 36) / nu;
+        if (cap > 64 * G) cap = 64 * G;
+        if (cap < 4 * G) cap = 4 * G;
+        tiny_cycle_scan_kernel<<<dim3(grid1(nu)), dim3(256), 0, ctx->stream>>>(uidx, ulf, nu, LF, (u32)(cap > 0xfffffff0ull ? 0xfffffff0ull : cap),
+                                                                              recs, ticket + 7, ticket + 4);
+        HIPC(hipGetLastError());
+    }
+    BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
     const u64 kc = ctx->h_small[SMI_COUNTERS + 2];
-    ctx->tm.unvisited = nu;
-    if (kc == 0 || kc > s_all) return BWTS_E_INTERNAL;
-    if (nu > UNV_CAP) { *retry = true; return BWTS_OK; }   // Theta(n) elements in tiny cycles
+    const u64 kt = ctx->h_small[SMI_COUNTERS + 7];
+    if (ctx->h_small[SMI_COUNTERS + 4]) { *retry = true; return BWTS_OK; }   // a cycle without a splitter too long for one lane
+    if (kc == 0 || kc > s2all || kt > nu) return BWTS_E_INTERNAL;
+    const u64 kall = kc + kt;
+    ctx->tm.factors = kall;
 
-    // host: order the cycles by smallest element (unbwts.c:62-77); splitter-free cycles join here
-    std::vector<CycleRec> recs(kc);
-    HIPC(hipMemcpyAsync(recs.data(), d_recs, kc * sizeof(CycleRec), hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<u32> h_uidx(nu), h_ulf(nu);
-    if (nu) {
-        HIPC(hipMemcpyAsync(h_uidx.data(), uidx, nu * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPC(hipMemcpyAsync(h_ulf.data(), ulf, nu * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIPC(hipStreamSynchronize(ctx->stream));
-
-    struct Cyc { u32 minelem, len; u32 leader; };   // leader = LR_NIL for a splitter-free cycle
-    std::vector<Cyc> cycles;
-    cycles.reserve(kc + 16);
-    for (const CycleRec &r : recs) cycles.push_back(Cyc{r.minelem, r.len, r.leader});
-    std::vector<u32> u_cyc(nu), u_t(nu);
-    if (nu) {
-        // the sweep appends in arbitrary order: sort (index, LF) pairs by index
-        std::vector<u32> ord(nu);
-        for (u64 q = 0; q < nu; q++) ord[q] = (u32)q;
-        std::sort(ord.begin(), ord.end(), [&](u32 a, u32 b) { return h_uidx[a] < h_uidx[b]; });
-        std::vector<u32> si(nu), sl(nu);
-        for (u64 q = 0; q < nu; q++) { si[q] = h_uidx[ord[q]]; sl[q] = h_ulf[ord[q]]; }
-        h_uidx.swap(si); h_ulf.swap(sl);
-        std::vector<u8> seen(nu, 0);
-        for (u64 q = 0; q < nu; q++) {
-            if (seen[q]) continue;
-            const u32 cid = (u32)cycles.size();
-            u64 at = q;
-            u32 t = 0;
-            do {
-                seen[at] = 1;
-                u_cyc[at] = cid; u_t[at] = t++;
-                const u32 nx = h_ulf[at];
-                const auto it = std::lower_bound(h_uidx.begin(), h_uidx.end(), nx);
-                if (it == h_uidx.end() || *it != nx) {
-                    if (mark == MARK_SENTINEL && n == 0x100000000ull) { *ambiguous = true; return BWTS_OK; }   // see the length check below
-                    return BWTS_E_INTERNAL;
-                }
-                at = (u64)(it - h_uidx.begin());
-            } while (at != q);
-            cycles.push_back(Cyc{h_uidx[q], t, LR_NIL});
-        }
-    }
-    ctx->tm.factors = cycles.size();
-    std::vector<u32> order(cycles.size());
-    for (size_t c = 0; c < order.size(); c++) order[c] = (u32)c;
-    std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return cycles[a].minelem < cycles[b].minelem; });
-    std::vector<u32> cyc_end(cycles.size());
-    std::vector<u32> h_lidx, h_lend;
-    h_lidx.reserve(kc); h_lend.reserve(kc);
+    // order the cycles by smallest element on the device: sort (minelem, record), prefix sums of the lengths
     {
-        u64 used = 0;
-        for (u32 c : order) {
-            cyc_end[c] = (u32)(n - 1 - used);
-            used += cycles[c].len;
-            if (cycles[c].leader != LR_NIL) { h_lidx.push_back(cycles[c].leader); h_lend.push_back(cyc_end[c]); }
-        }
-        if (used != n) {
-            // n = 2^32 only: the one entry whose value equals LF_VISITED sat in a splitter-free cycle and was taken for visited
-            if (mark == MARK_SENTINEL && n == 0x100000000ull) { *ambiguous = true; return BWTS_OK; }
-            return BWTS_E_INTERNAL;
-        }
-    }
-    HIPC(hipMemcpyAsync(tmp_idx, h_lidx.data(), kc * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPC(hipMemcpyAsync(tmp_val, h_lend.data(), kc * 4, hipMemcpyHostToDevice, ctx->stream));
-    {
-        SpanGuard sg(ctx, BWTS_K_LISTRANK, s_all, 0);
-        scatter_u32_kernel<<<dim3(grid1(kc)), dim3(256), 0, ctx->stream>>>(tmp_idx, tmp_val, kc, end_by_leader);
-        lr_place_kernel<<<dim3(grid1(s_all)), dim3(256), 0, ctx->stream>>>(s_all, lrmin[cur], lrsum[sc], dist, min_dist, end_by_leader, d_opos, d_wrap, d_clen);
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, kall, 0);
+        HIPC(hipMemcpyAsync(recs + kt, d_recs2, kc * sizeof(CycleRec), hipMemcpyDeviceToDevice, ctx->stream));
+        char *sb = nullptr;
+        const size_t k8 = align_up(kall * 8, 256), k4 = align_up(kall * 4, 256);
+        BWTS_TRY(aux_reserve_slot(ctx, 1, 2 * k8 + 2 * k4 + radix_tile_hist_bytes(kall) + scan_temp_bytes(kall) + 4096, &sb));
+        SortPlan cp;
+        cp.keys[0] = (u64 *)sb; cp.keys[1] = (u64 *)(sb + k8);
+        cp.vals[0] = (u32 *)(sb + 2 * k8); cp.vals[1] = (u32 *)(sb + 2 * k8 + k4);
+        cp.tile_hist = (u32 *)(sb + 2 * k8 + 2 * k4);
+        cp.scan_temp = sb + 2 * k8 + 2 * k4 + radix_tile_hist_bytes(kall);
+        cycle_keys_kernel<<<dim3(grid1(kall)), dim3(256), 0, ctx->stream>>>(recs, kall, cp.keys[0], cp.vals[0]);
+        int res = 0;
+        int kbits = 0; for (u64 x = n - 1; x; x >>= 1) kbits++;
+        BWTS_TRY(radix_sort_pairs(ctx, cp, kall, kbits < 1 ? 1 : kbits, &res));
+        CycleLenIn lin{recs, cp.vals[res]};
+        CycleEndOut lout{recs, cp.vals[res], kall, (u32)(n - 1), end_by_leader, end_of_rec, ctx->d_small + SMI_COUNTERS + 13};
+        BWTS_TRY((device_scan<false, u32>(ctx, kall, lin, lout, OpAdd(), 0u, cp.scan_temp)));
+        lr_place2_kernel<<<dim3(grid1(s2all)), dim3(256), 0, ctx->stream>>>(s2all, lrmin[cur], lrsum[sc], dist, min_dist, end_by_leader, place2);
+        lr2_distribute_kernel<<<dim3(grid1(s2all)), dim3(256), 0, ctx->stream>>>(noderec, s2, s2all, U, place2, d_opos, d_wrap, d_clen);
         HIPC(hipGetLastError());
     }
 
@@ -811,28 +984,17 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         if (tpn_log2 < 0) tpn_log2 = 0;
         if (tpn_log2 > 8) tpn_log2 = 8;
         const u64 threads = s_all << tpn_log2;
-        place_segments_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(seg, s_all, slot, tpn_log2, seglen,
+        place_segments_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(seg, s_all, slot, tpn_log2, noderec,
                                                                                                       d_opos, d_wrap, d_clen, d_out);
+        if (kt) tiny_place_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(recs, kt, end_of_rec, LF, dC, d_out);
         HIPC(hipGetLastError());
     }
-    // elements of splitter-free cycles
-    std::vector<u32> h_upos;
-    std::vector<u8> h_usym;
-    if (nu) {
-        h_upos.resize(nu); h_usym.resize(nu);
-        for (u64 q = 0; q < nu; q++) {
-            h_upos[q] = cyc_end[u_cyc[q]] - u_t[q];
-            const u64 *it = std::upper_bound(hC, hC + 257, (u64)h_ulf[q]);
-            h_usym[q] = (u8)((it - hC) - 1);
-        }
-        u32 *d_upos = uidx;                                           // the index list is no longer needed
-        u8 *d_usym = (u8 *)(ub + 2 * align_up(UNV_CAP * 4, 256));
-        HIPC(hipMemcpyAsync(d_upos, h_upos.data(), nu * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPC(hipMemcpyAsync(d_usym, h_usym.data(), nu, hipMemcpyHostToDevice, ctx->stream));
-        scatter_bytes_kernel<<<dim3(grid1(nu)), dim3(256), 0, ctx->stream>>>(d_upos, d_usym, nu, d_out);
-        HIPC(hipGetLastError());
+    BWTS_TRY(read_small(ctx, SMI_COUNTERS + 13, 1));
+    if ((u32)ctx->h_small[SMI_COUNTERS + 13] != (u32)n) {
+        // n = 2^32 only: the one entry whose value equals LF_VISITED sat in a cycle without a splitter and was taken for visited
+        if (mark == MARK_SENTINEL && n == 0x100000000ull) { *ambiguous = true; return BWTS_OK; }
+        return BWTS_E_INTERNAL;
     }
-    HIPC(hipStreamSynchronize(ctx->stream));   // host vectors above must outlive the copies
     return BWTS_OK;
 }
 
@@ -847,7 +1009,7 @@ int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     if (me && !strcmp(me, "sentinel")) mark = MARK_SENTINEL;
     if ((me && !strcmp(me, "bytemap")) || getenv("BWTS_BYTEMARK")) mark = MARK_BYTEMAP;
     BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous));
-    if (ambiguous) {            // sentinel marks only, n = 2^32: 0xffffffff was a real entry of a splitter-free cycle
+    if (ambiguous) {            // sentinel marks only, n = 2^32: 0xffffffff was a real entry of a cycle without a splitter
         mark = MARK_BYTEMAP;
         BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous));
     }

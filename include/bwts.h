@@ -78,6 +78,7 @@ typedef struct bwts_timings {
     uint32_t key_bits;            /* bits of a round-0 key                                */
     uint64_t active_after_round0; /* elements still tied after round 0                    */
     uint64_t unvisited;           /* inverse: elements in cycles without a splitter       */
+    uint64_t device_bytes;        /* device memory the context holds after the call (arenas, staging copies of in/out) */
     uint64_t round_active[BWTS_MAX_ROUND_STATS]; /* forward: elements still tied when sort round r+1 starts (r = 0: after round 0) */
     bwts_kernel_stat k[BWTS_K_COUNT];
 } bwts_timings;

@@ -1,0 +1,10 @@
+#!/bin/bash
+# usage: tools/gpu_call.sh <timeout_s> <session script>   -- runs the script on a GPU box; waits while the pool has no free box (exit 3)
+T=$1; S=$2
+for try in $(seq 1 40); do
+  /usr/local/graft/bin/gpurun --timeout $T -- "bash $S"
+  rc=$?
+  if [ $rc -ne 3 ]; then exit $rc; fi
+  sleep 90
+done
+exit 3
