@@ -1192,6 +1192,38 @@ __global__ __launch_bounds__(256) void rank_scatter_pairs_kernel(const u64 *__re
     for (u32 e = lo + threadIdx.x; e < hi; e += 256) { const uint2 v = src[e]; rank[v.x] = v.y; }
 }
 
+// Second form of the same build, the one in use: one u64 per slot, (head << 32) | position, sorted on the position's top 16 bits
+// by two keys-only radix passes (16 bytes per element and pass, ballot-ranked like every other pass -- the LDS atomics of
+// rank_partition_kernel made that single pass cost 30 ms at n = 2^30), then rank[position] = head with all writes of a
+// workgroup inside a window of n / 2^16 positions.
+__global__ __launch_bounds__(256) void rank_keys_kernel(const u32 *__restrict__ SA, u64 n, const u64 *__restrict__ headw,
+                                                        const u64 *__restrict__ pre, u64 *__restrict__ keys)
+{
+    const int lane = lane_id();
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < ((n + 63) & ~63ull); i += (u64)gridDim.x * 256) {
+        const u64 w = i >> 6;                               // the 64-slot word is the same for the whole wave
+        if (i < n) {
+            const u64 hm = headw[w], pr = pre[w];
+            const u64 below = lane == 63 ? hm : hm & ((2ull << lane) - 1ull);
+            const u32 h = below ? (u32)((w << 6) + (u64)(63 - __clzll((long long)below))) : (u32)(pr >> 32);
+            keys[i] = ((u64)h << 32) | (u64)SA[i];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void rank_apply_kernel(const u64 *__restrict__ keys, u64 n, u32 *__restrict__ rank)
+{
+    // consecutive keys -> consecutive windows: a workgroup's writes stay inside a few hundred KB
+    const u64 per = 4096;
+    for (u64 base = (u64)blockIdx.x * per; base < n; base += (u64)gridDim.x * per) {
+        const u64 end = base + per < n ? base + per : n;
+        for (u64 i = base + threadIdx.x; i < end; i += 256) { const u64 kv = keys[i]; rank[(u32)kv] = (u32)(kv >> 32); }
+    }
+}
+__global__ void count_tied_kernel(const u64 *__restrict__ keepw, const u64 *__restrict__ pre, u64 words, u64 *__restrict__ cnt_active)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cnt_active = (u64)(u32)pre[words - 1] + (u64)__popcll(keepw[words - 1]);
+}
+
 // ---- later rounds: sorting inside groups ------------------------------------------------------------------------------
 // The tied list is ordered by group (heads increase along it), so a round's sort by (head, successor rank) only has to
 // order each group by the rank.  On real text most tied elements sit in small groups (53 MiB of source text: 62 % of all
@@ -1310,10 +1342,10 @@ __global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restric
 // Larger groups (a few per cent of the elements after the first rounds) are flagged, compacted, ordered by the radix
 // sort, regrouped with a scan and put back.  A stable compaction of the surviving elements gives the next round's list.
 #define DG_CAP     16
-#define DG_THREADS 256
-#define DG_ITEMS   8
-#define DG_TILE    (DG_THREADS * DG_ITEMS)
-#define DG_SPAN    (DG_TILE + 2 * DG_CAP + 1)   // + 1: the slot that shows where a group ending at the last tail slot ends
+#define DG_THREADS 512
+#define DG_ITEMS   2
+#define DG_SPAN    (DG_THREADS * DG_ITEMS)            // list elements a workgroup looks at
+#define DG_OWN     (DG_SPAN - 2 * DG_CAP - 1)         // ... and decides: DG_CAP in front and DG_CAP + 1 behind are only looked at
 #define DG_FS_LDS  1024                  // factor starts kept in LDS when there are at most this many
 enum { DG_DONE = 0, DG_KEEP = 1, DG_BIG = 2, DG_MOVED = 4 };      // state: low bits = what happens to the element; DG_MOVED: its head (= rank) changed
 
@@ -1328,9 +1360,14 @@ struct PrevSym {       // T[cprev(p)] (mk_bwts_sa.c:172-188): from the P array w
     }
 };
 
+// Workgroup w looks at list elements [w * DG_OWN - DG_CAP, ... + DG_SPAN): LDS slot sl <-> element e = w * DG_OWN - DG_CAP + sl,
+// thread t holds slots t and t + DG_THREADS (consecutive lanes = consecutive slots, so a wave's group-start flags are one
+// __ballot).  It decides the elements of slots [DG_CAP, DG_CAP + DG_OWN): a group of at most DG_CAP members that starts
+// there is ordered here, whole (its members reach at most DG_CAP - 1 slots further, and the slot after them shows its end);
+// an element of that range whose group is larger is flagged DG_BIG.
 // counters: [1] elements of larger groups, [2] a group split.  rank[] is only read here: the new ranks are applied by the
-// compaction pass at the end of the round (DgKeepOut) -- a round's keys must all come from the same version of the ranks:
-// a member that already shows its new rank next to a group-mate that still shows the old one would order the wrong way.
+// compaction pass at the end of the round (dg_compact_kernel) -- a round's keys must all come from the same version of the
+// ranks: a member that already shows its new rank next to a group-mate that still shows the old one would order the wrong way.
 template <bool CYCLIC>
 __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, u64 a,
                                                                  const u32 *__restrict__ rank, u64 n, u64 h,
@@ -1339,85 +1376,92 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
                                                                  PrevSym prev, u8 *__restrict__ out /* null: no emission */,
                                                                  unsigned long long *__restrict__ counters)
 {
-    __shared__ u32 hd[DG_SPAN];          // group heads of the tile and DG_CAP elements on either side
-    __shared__ u32 key[DG_SPAN];         // successor ranks of the members of the groups this tile owns
+    __shared__ u32 hd[DG_SPAN];              // group heads
+    __shared__ u32 key[DG_SPAN];             // successor ranks of the members of the groups this workgroup orders
+    __shared__ u64 startm[DG_SPAN / 64];     // bit = a group starts at this slot (an element outside the list counts as a start)
     __shared__ u32 fs[DG_FS_LDS];
     __shared__ u32 cnt_big, any_split;
-    const int tid = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * DG_TILE;              // list index of LDS slot DG_CAP
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long long e0 = (long long)blockIdx.x * DG_OWN - DG_CAP;     // list element of slot 0
     if (tid == 0) { cnt_big = 0; any_split = 0; }
     const bool fs_lds = CYCLIC && k <= DG_FS_LDS;
     if (fs_lds) for (u32 i = tid; i < k; i += DG_THREADS) fs[i] = fstart[i];
-    for (u32 sl = tid; sl < DG_SPAN; sl += DG_THREADS) {
-        const long long e = (long long)base - DG_CAP + sl;
-        hd[sl] = (e >= 0 && (u64)e < a) ? head[e] : 0xffffffffu;       // outside the list: never equal to a neighbour's head? see below
+    bool valid[DG_ITEMS];
+    u32 myh[DG_ITEMS];
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const long long e = e0 + j * DG_THREADS + tid;
+        valid[j] = e >= 0 && (u64)e < a;
+        myh[j] = valid[j] ? head[e] : 0u;
+        hd[j * DG_THREADS + tid] = myh[j];
     }
     __syncthreads();
-    // slot sl holds list element e = base - DG_CAP + sl.  Elements outside [0, a) must not join a group: heads are slots
-    // < n <= 2^32 - 1 except for n = 2^32, so equality is tested together with the bounds.
-    auto same = [&](u32 x, u32 y) -> bool {       // do slots x and y (adjacent) belong to one group?
-        const long long ex = (long long)base - DG_CAP + x, ey = (long long)base - DG_CAP + y;
-        return ex >= 0 && ey >= 0 && (u64)ex < a && (u64)ey < a && hd[x] == hd[y];
-    };
-    // every thread looks after DG_ITEMS slots of [DG_CAP, DG_CAP + DG_TILE + DG_CAP): the tile's own elements and the
-    // DG_CAP behind them (members of an owned group may reach that far)
-    u32 my_idx[DG_ITEMS + 1], my_gs[DG_ITEMS + 1];
-    u8 my_sz[DG_ITEMS + 1], my_kind[DG_ITEMS + 1];            // kind: 0 nothing to do here, 1 member of an owned small group, 2 own element of a large group
 #pragma unroll
-    for (int j = 0; j <= DG_ITEMS; j++) {
-        my_kind[j] = 0; my_idx[j] = 0; my_gs[j] = 0; my_sz[j] = 0;
-        // slots DG_CAP + j * DG_THREADS + tid; the extra round (j == DG_ITEMS) covers the DG_CAP slots behind the tile
-        const u32 sl = DG_CAP + (u32)j * DG_THREADS + tid;
-        if (j == DG_ITEMS && tid >= DG_CAP) continue;
-        const u64 e = base + (u64)(sl - DG_CAP);
-        if (e >= a) continue;
-        // group start: walk back while the neighbour belongs to the same group (at most DG_CAP steps)
-        u32 gs = sl, steps = 0;
-        while (steps < DG_CAP && gs > 0 && same(gs - 1, gs)) { gs--; steps++; }
-        const bool start_seen = gs > 0 && !same(gs - 1, gs);
-        u32 ge = sl + 1;                                       // one past the last member seen
-        steps = 0;
-        while (steps < DG_CAP && ge < DG_SPAN && same(ge - 1, ge)) { ge++; steps++; }
-        const bool end_seen = ge < DG_SPAN && !same(ge - 1, ge);
-        const bool small = start_seen && end_seen && ge - gs <= DG_CAP;
-        const bool own_elem = sl < DG_CAP + DG_TILE;
-        if (small) {
-            if (gs >= DG_CAP && gs < DG_CAP + DG_TILE) { my_kind[j] = 1; my_gs[j] = gs; my_sz[j] = (u8)(ge - gs); }
-        } else if (own_elem) my_kind[j] = 2;
-        if (my_kind[j]) my_idx[j] = idx[e];
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const u32 sl = (u32)j * DG_THREADS + tid;
+        const long long e = e0 + sl;
+        const bool prev_valid = e - 1 >= 0 && (u64)(e - 1) < a;
+        // slot 0 has no visible predecessor: it is never decided here, its flag only has to stop nobody (not a start)
+        const bool st = sl > 0 && (!valid[j] || !prev_valid || myh[j] != hd[sl - 1]);
+        const u64 m = __ballot(st);
+        if (lane == 0) startm[sl >> 6] = m;
     }
-    // successor ranks of the owned members: all of a thread's gathers are in flight together
-    u32 my_key[DG_ITEMS + 1];
+    __syncthreads();
+    u32 my_idx[DG_ITEMS], my_gs[DG_ITEMS], my_sz[DG_ITEMS], my_kind[DG_ITEMS];   // kind: 0 nothing to do here, 1 member of a group ordered here, 2 own element of a larger group
 #pragma unroll
-    for (int j = 0; j <= DG_ITEMS; j++) {
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const u32 sl = (u32)j * DG_THREADS + tid;
+        my_kind[j] = 0; my_idx[j] = 0; my_gs[j] = 0; my_sz[j] = 0;
+        if (!valid[j]) continue;
+        // last start at or before sl, first start after sl: bit scans over at most two 64-slot words each
+        const u32 w = sl >> 6, b = sl & 63u;
+        const u64 cur = startm[w];
+        const u64 below = b == 63 ? cur : cur & ((2ull << b) - 1ull);
+        int gs = -1;
+        if (below) gs = (int)(w * 64 + 63 - (u32)__clzll((long long)below));
+        else if (w > 0) { const u64 pm = startm[w - 1]; if (pm) gs = (int)((w - 1) * 64 + 63 - (u32)__clzll((long long)pm)); }
+        const u64 above = b == 63 ? 0ull : cur >> (b + 1);
+        int ge = -1;
+        if (above) ge = (int)(sl + 1 + (u32)__ffsll((unsigned long long)above) - 1);
+        else if (w + 1 < DG_SPAN / 64) { const u64 nm = startm[w + 1]; if (nm) ge = (int)((w + 1) * 64 + (u32)__ffsll((unsigned long long)nm) - 1); }
+        const bool small = gs >= 1 && ge >= 0 && ge - gs <= DG_CAP;
+        if (small) {
+            if (gs >= DG_CAP && gs < DG_CAP + DG_OWN) { my_kind[j] = 1; my_gs[j] = (u32)gs; my_sz[j] = (u32)(ge - gs); }
+        } else if (sl >= DG_CAP && sl < DG_CAP + DG_OWN) my_kind[j] = 2;
+        if (my_kind[j]) my_idx[j] = idx[e0 + sl];
+    }
+    // successor ranks of the members ordered here
+    u32 my_key[DG_ITEMS];
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
         my_key[j] = 0;
         if (my_kind[j] != 1) continue;
         const u64 p = my_idx[j];
         if (CYCLIC) {
-            u64 f;
-            if (fs_lds) {
-                u64 lo = 0, hi = k - 1;
-                while (lo < hi) { const u64 mid = (lo + hi + 1) >> 1; if ((u64)fs[mid] <= p) lo = mid; else hi = mid - 1; }
-                f = lo;
-            } else f = factor_of(fstart, k, p);
-            const u64 s0 = fs_lds ? fs[f] : fstart[f];
-            const u64 e0 = f + 1 < k ? (u64)(fs_lds ? fs[f + 1] : fstart[f + 1]) : n;
-            my_key[j] = rank[cyclic_successor(p, s0, e0 - s0, h)];
+            u64 lo = 0, hi = k - 1;
+            if (fs_lds) { while (lo < hi) { const u64 mid = (lo + hi + 1) >> 1; if ((u64)fs[mid] <= p) lo = mid; else hi = mid - 1; } }
+            else lo = factor_of(fstart, k, p);
+            const u64 s0 = fs_lds ? fs[lo] : fstart[lo];
+            const u64 e1 = lo + 1 < k ? (u64)(fs_lds ? fs[lo + 1] : fstart[lo + 1]) : n;
+            my_key[j] = rank[cyclic_successor(p, s0, e1 - s0, h)];
         } else {
             const u64 q = p + h;
             my_key[j] = q < n ? rank[q] + 1u : 0u;
         }
     }
 #pragma unroll
-    for (int j = 0; j <= DG_ITEMS; j++)
-        if (my_kind[j] == 1) key[DG_CAP + (u32)j * DG_THREADS + tid] = my_key[j];
+    for (int j = 0; j < DG_ITEMS; j++)
+        if (my_kind[j] == 1) key[j * DG_THREADS + tid] = my_key[j];
     __syncthreads();
+    // order inside the group by counting; results first, then the loads of the emission, then every store
+    u32 dst_off[DG_ITEMS], newhead[DG_ITEMS], st_out[DG_ITEMS];
+    bool alone[DG_ITEMS];
     u32 big_here = 0, split_here = 0;
 #pragma unroll
-    for (int j = 0; j <= DG_ITEMS; j++) {
-        const u32 sl = DG_CAP + (u32)j * DG_THREADS + tid;
-        const u64 e = base + (u64)(sl - DG_CAP);
-        if (my_kind[j] == 2) { oidx[e] = my_idx[j]; ohead[e] = hd[sl]; state[e] = DG_BIG; big_here++; }
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const u32 sl = (u32)j * DG_THREADS + tid;
+        dst_off[j] = sl; newhead[j] = myh[j]; st_out[j] = DG_BIG; alone[j] = false;
+        if (my_kind[j] == 2) big_here++;
         if (my_kind[j] != 1) continue;
         const u32 gs = my_gs[j], sz = my_sz[j], mine = my_key[j];
         u32 less = 0, eq = 0, eq_before = 0;
@@ -1427,12 +1471,21 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
             eq += ko == mine ? 1u : 0u;
             eq_before += (ko == mine && gs + m < sl) ? 1u : 0u;
         }
-        const u32 oldhead = hd[sl], newhead = oldhead + less;
-        const u64 dst = base + (u64)(gs - DG_CAP) + less + eq_before;
-        const bool alone = eq == 1;
-        oidx[dst] = my_idx[j]; ohead[dst] = newhead; state[dst] = (u8)((alone ? DG_DONE : DG_KEEP) | (less ? DG_MOVED : 0));
-        if (alone && out) out[newhead] = prev(my_idx[j]);
+        dst_off[j] = gs + less + eq_before;
+        newhead[j] = myh[j] + less;
+        alone[j] = eq == 1;
+        st_out[j] = (alone[j] ? DG_DONE : DG_KEEP) | (less ? DG_MOVED : 0);
         split_here |= eq < sz ? 1u : 0u;
+    }
+    u32 pv[DG_ITEMS];
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) pv[j] = (out && alone[j]) ? (u32)prev(my_idx[j]) : 0u;
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        if (!my_kind[j]) continue;
+        const u64 dst = (u64)(e0 + (long long)dst_off[j]);
+        oidx[dst] = my_idx[j]; ohead[dst] = newhead[j]; state[dst] = (u8)st_out[j];
+        if (out && alone[j]) out[newhead[j]] = (u8)pv[j];
     }
     if (big_here) atomicAdd(&cnt_big, big_here);
     if (split_here) any_split = 1;
@@ -1522,25 +1575,67 @@ struct DgRegroupOut {
     }
 };
 
-// end of a round: the new ranks are written, the elements that stay are compacted (stable) into the next round's list
-struct DgKeepIn {
-    const u8 *state;
-    __device__ __forceinline__ u32 operator()(u64 i) const { return (state[i] & 3) == DG_KEEP ? 1u : 0u; }
-};
-struct DgKeepOut {
-    const u8 *state; const u32 *oidx; const u32 *ohead; u32 *rank; u32 *n_idx; u32 *n_head; u64 a; u64 *count;
-    __device__ __forceinline__ void operator()(u64 i, u32 before) const
-    {
-        const u32 st = state[i];
-        const bool keep = (st & 3) == DG_KEEP;
-        if ((st & DG_MOVED) || keep) {
-            const u32 p = oidx[i], hd = ohead[i];
-            if (st & DG_MOVED) rank[p] = hd;
-            if (keep) { n_idx[before] = p; n_head[before] = hd; }
-        }
-        if (i + 1 == a) *count = (u64)before + (keep ? 1u : 0u);
+// end of a round: the new ranks are written, the elements that stay are compacted (stable) into the next round's list.
+// Two sweeps: per-tile counts of the elements that stay (the state bytes only), exclusive scan of the counts, then the
+// move -- every load of a thread before its first store (the generic scan's output functor runs element by element, and
+// its stores kept the next element's loads waiting).
+#define DC_THREADS 256
+#define DC_ITEMS   8
+#define DC_TILE    (DC_THREADS * DC_ITEMS)
+__global__ __launch_bounds__(DC_THREADS) void dg_count_kernel(const u8 *__restrict__ state, u64 a, u32 *__restrict__ partial)
+{
+    __shared__ u32 wsum[DC_THREADS / 64];
+    const u64 base = (u64)blockIdx.x * DC_TILE;
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < DC_ITEMS; j++) {
+        const u64 i = base + (u64)j * DC_THREADS + threadIdx.x;
+        if (i < a && (state[i] & 3) == DG_KEEP) c++;
     }
-};
+    c = wave_scan_inclusive(c, OpAdd());
+    if (lane_id() == 63) wsum[wave_id()] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 t = 0; for (int w = 0; w < DC_THREADS / 64; w++) t += wsum[w]; partial[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(DC_THREADS) void dg_compact_kernel(const u8 *__restrict__ state, const u32 *__restrict__ oidx,
+                                                                const u32 *__restrict__ ohead, u64 a, const u32 *__restrict__ partial,
+                                                                u32 *__restrict__ rank, u32 *__restrict__ n_idx, u32 *__restrict__ n_head,
+                                                                u64 *__restrict__ count)
+{
+    __shared__ u32 scan_sm[DC_THREADS / 64];
+    // blocked: thread t owns elements [8 t, 8 t + 8) of the tile, so its kept elements are consecutive in the output
+    const u64 i0 = (u64)blockIdx.x * DC_TILE + (u64)threadIdx.x * DC_ITEMS;
+    u32 st[DC_ITEMS], p[DC_ITEMS], hd[DC_ITEMS];
+    if (i0 + DC_ITEMS <= a) {
+        const uint2 sv = *(const uint2 *)(state + i0);                      // i0 is a multiple of 8
+        const uint4 p0 = *(const uint4 *)(oidx + i0), p1 = *(const uint4 *)(oidx + i0 + 4);
+        const uint4 h0 = *(const uint4 *)(ohead + i0), h1 = *(const uint4 *)(ohead + i0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { st[j] = (sv.x >> (8 * j)) & 255u; st[4 + j] = (sv.y >> (8 * j)) & 255u; }
+        p[0] = p0.x; p[1] = p0.y; p[2] = p0.z; p[3] = p0.w; p[4] = p1.x; p[5] = p1.y; p[6] = p1.z; p[7] = p1.w;
+        hd[0] = h0.x; hd[1] = h0.y; hd[2] = h0.z; hd[3] = h0.w; hd[4] = h1.x; hd[5] = h1.y; hd[6] = h1.z; hd[7] = h1.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < DC_ITEMS; j++) {
+            const u64 i = i0 + j;
+            st[j] = i < a ? state[i] : (u32)DG_DONE;
+            p[j] = i < a ? oidx[i] : 0u;
+            hd[j] = i < a ? ohead[i] : 0u;
+        }
+    }
+    u32 mine = 0;
+#pragma unroll
+    for (int j = 0; j < DC_ITEMS; j++) mine += (st[j] & 3) == DG_KEEP ? 1u : 0u;
+    u32 total;
+    u32 at = partial[blockIdx.x] + block_scan_exclusive<u32, OpAdd, DC_THREADS / 64>(mine, OpAdd(), 0u, scan_sm, &total);
+#pragma unroll
+    for (int j = 0; j < DC_ITEMS; j++) {
+        if (st[j] & DG_MOVED) rank[p[j]] = hd[j];
+        if ((st[j] & 3) == DG_KEEP) { n_idx[at] = p[j]; n_head[at] = hd[j]; at++; }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == DC_THREADS - 1) *count = (u64)at;
+}
+
 // what is left when no group splits any more: equal infinite words (mk_bwts_sa.c ties only between identical rotations, which
 // emit identical bytes).  The members of such a group take the group's slots in list order.
 struct DgRestIn {
@@ -1603,7 +1698,7 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
         {
             SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 29 * a);       // idx, head in; idx, head, state out; one rank gather
-            const unsigned blocks = (unsigned)((a + DG_TILE - 1) / DG_TILE);
+            const unsigned blocks = (unsigned)((a + DG_OWN - 1) / DG_OWN);
             dense_round_kernel<CYCLIC><<<dim3(blocks), dim3(DG_THREADS), 0, ctx->stream>>>(
                 cur.idx, cur.head, a, sp.rank, n, h, d_fstart, k, t_idx, t_head, state, prev, out, (unsigned long long *)cnt);
             HIPC(hipGetLastError());
@@ -1642,9 +1737,13 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         }
         {
             SpanGuard g(ctx, BWTS_K_RERANK, a, 18 * a);
-            DgKeepIn kin{state};
-            DgKeepOut kout{state, t_idx, t_head, sp.rank, sets[nxt].idx, sets[nxt].head, a, cnt + 0};
-            BWTS_TRY((device_scan<false, u32>(ctx, a, kin, kout, OpAdd(), 0u, sp.scan_temp)));
+            const u64 tiles = (a + DC_TILE - 1) / DC_TILE;
+            u32 *partial = (u32 *)sp.scan_temp;
+            dg_count_kernel<<<dim3((unsigned)tiles), dim3(DC_THREADS), 0, ctx->stream>>>(state, a, partial);
+            BWTS_TRY((device_scan_partials<u32, OpAdd>(ctx, tiles, OpAdd(), 0u, sp.scan_temp)));
+            dg_compact_kernel<<<dim3((unsigned)tiles), dim3(DC_THREADS), 0, ctx->stream>>>(state, t_idx, t_head, a, partial, sp.rank, sets[nxt].idx,
+                                                                                          sets[nxt].head, cnt + 0);
+            HIPC(hipGetLastError());
         }
         BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
         const u64 a_new = ctx->h_small[SM_COUNTERS + 0];
@@ -1710,6 +1809,9 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
 
     HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
     const u64 *flag_heads = nullptr, *flag_pre = nullptr;     // set when the round-0 flag words survive outside sp.rank
+    const u64 *flag_heads_any = nullptr, *flag_pre_any = nullptr, *flag_keep = nullptr;   // the flag words wherever they live
+    u64 flag_words = 0;
+    bool rank_early = false;                                  // the dense rank array was built before the tied list
     static const bool scan_by_keys = [] { const char *e = getenv("BWTS_GROUPSCAN"); return e && !strcmp(e, "keys"); }();
     if (scan_by_keys) {             // the element-wise scan the later rounds use (kept selectable for tests)
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
@@ -1732,19 +1834,46 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         WordIn in{headw, keepw};
         ScanStoreArr<u64> out{pre};
         BWTS_TRY((device_scan<false, u64>(ctx, words, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
-        waves = (words + 63) / 64;
-        blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
-        tied_from_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(headw, keepw, pre, n, SA, cur.idx, cur.slot, cur.head, cnt + 0);
+        count_tied_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(keepw, pre, words, cnt + 0);
         HIPC(hipGetLastError());
+        flag_keep = keepw; flag_words = words;
+        flag_heads_any = headw; flag_pre_any = pre;
     }
     BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
     u64 a = ctx->h_small[CNT_ACTIVE];
     *active0_out = a;
     if (CYCLIC) ctx->tm.round_active[0] = a;
+    bool rank_valid = false;
+    if (flag_keep) {
+        // Many ties: the dense rank array.  It is built BEFORE the tied list, while the list's future home (the other key
+        // buffer) is still free: the build sorts one u64 per slot between that buffer and the sorted keys' (not needed any
+        // more without the sparse rank map).
+        static const bool plain_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
+        static const bool part_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "partition"); }();
+        if (a > n / 32 && flag_heads && n >= (1ull << 22) && !plain_build && !part_build) {
+            SpanGuard g(ctx, BWTS_K_RERANK, n, 28 * n);
+            u64 *rk[2] = {sp.keys[res ^ 1], K0};
+            u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+            rank_keys_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(SA, n, flag_heads, flag_pre, rk[0]);
+            HIPC(hipGetLastError());
+            const int pb = bitlen_u64(n - 1);
+            int rres = 0;
+            BWTS_TRY(radix_sort_keys(ctx, rk, sp.tile_hist, sp.scan_temp, n, pb - 16, 16, &rres));
+            blocks = (n + 4095) / 4096; if (blocks > 65536) blocks = 65536;
+            rank_apply_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(rk[rres], n, sp.rank);
+            HIPC(hipGetLastError());
+            rank_valid = true;
+            rank_early = true;
+        }
+        SpanGuard g(ctx, BWTS_K_RERANK, a, 12 * a);
+        const u64 waves = (flag_words + 63) / 64;
+        const unsigned blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
+        tied_from_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(flag_heads_any, flag_keep, flag_pre_any, n, SA, cur.idx, cur.slot, cur.head, cnt + 0);
+        HIPC(hipGetLastError());
+    }
     sp.tie_slots = cur.slot;        // stays untouched by the later rounds
     sp.tie_count = a;
     u32 rounds = 1;
-    bool rank_valid = false;
     ActiveList none{nullptr, nullptr, nullptr};
 
     if (a > 0) {
@@ -1812,8 +1941,10 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             HIPC(hipGetLastError());
         } else {
             static const bool plain_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
-            if (flag_heads && n >= (1ull << 22) && !plain_build) {
-                // binned: pairs go through the sorted keys' buffer (not needed without the sparse map), counters through the tile table
+            if (rank_early) {
+                // built before the tied list (see above)
+            } else if (flag_heads && n >= (1ull << 22) && !plain_build) {
+                // BWTS_RANKBUILD=partition: the first binned form.  Pairs go through the sorted keys' buffer (not needed without the sparse map), counters through the tile table
                 SpanGuard g(ctx, BWTS_K_RERANK, n, 28 * n);
                 int wlog = bitlen_u64(n - 1) - 12;
                 if (wlog < 18) wlog = 18;

@@ -151,6 +151,7 @@ size_t radix_tile_hist_bytes(u64 m);
 // Sorts on key bits [0, key_bits); returns in *result_buf which of keys[]/vals[] holds the output.
 int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, int *result_buf);
 int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp);
+int radix_sort_keys(bwts_ctx *ctx, u64 *keys[2], u32 *tile_hist, void *scan_temp, u64 m, int lo_bit, int bits, int *result_buf);
 
 // ---- forward / inverse drivers ----------------------------------------------------
 int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out);

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void radix_chunk_apply_kernel(u32 *__restrict_
 // one-byte stream), the per-wave digit counters are 16-bit and each slot's digit is kept in a byte table, so
 // the destination of a slot is re-derived instead of living in a register: 9 B of LDS per element instead
 // of 12, two 8192-element tiles fit a CU and one tile's loads overlap the other's ranking.
-template <int RX_THREADS, int RX_ITEMS, int MINW, bool HAS_SYM, bool IDENT>
+template <int RX_THREADS, int RX_ITEMS, int MINW, bool HAS_SYM, bool IDENT, bool KEYS_ONLY = false>
 __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const u64 *__restrict__ kin, const u32 *__restrict__ vin,
                                                                      u64 *__restrict__ kout, u32 *__restrict__ vout,
                                                                      const u32 *__restrict__ tile_off, u64 m, int shift,
@@ -238,12 +238,14 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
         }
     }
     // the keys' registers are free: the value (and byte) loads overlap the key write-out
-    u32 val[RX_ITEMS];
+    u32 val[KEYS_ONLY ? 1 : RX_ITEMS];
     u32 sym[HAS_SYM ? RX_ITEMS : 1];
+    if (!KEYS_ONLY) {
 #pragma unroll
-    for (int j = 0; j < RX_ITEMS; j++) {
-        const u64 i = wave_base + (u64)j * 64 + lane;
-        val[j] = IDENT ? (u32)i : (i < m ? vin[i] : 0u);          // first pass of a sort over positions: value = index
+        for (int j = 0; j < RX_ITEMS; j++) {
+            const u64 i = wave_base + (u64)j * 64 + lane;
+            val[KEYS_ONLY ? 0 : j] = IDENT ? (u32)i : (i < m ? vin[i] : 0u);          // first pass of a sort over positions: value = index
+        }
     }
     if (HAS_SYM) {
         // one register per byte and no arithmetic on them here: the 16 loads issue back to back (packing them
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
             }
         }
     }
+    if (KEYS_ONLY) return;                                          // a sort of bare keys (the payload sits in their upper bits)
     __syncthreads();
     // second trip through the same LDS: the value, with the travelling byte in the upper half of the slot
 #pragma unroll
@@ -282,8 +285,8 @@ __global__ __launch_bounds__(RX_THREADS, MINW) void radix_scatter2_kernel(const 
         const bool valid = wave_base + (u64)j * 64 + lane < m;
         const u32 p = POS_GET(j);
         if (valid) {
-            if (HAS_SYM) stage[p] = (u64)val[j] | ((u64)sym[j] << 32);
-            else ((u32 *)stage)[p] = val[j];
+            if (HAS_SYM) stage[p] = (u64)val[KEYS_ONLY ? 0 : j] | ((u64)sym[j] << 32);
+            else ((u32 *)stage)[p] = val[KEYS_ONLY ? 0 : j];
         }
     }
     __syncthreads();
@@ -746,6 +749,33 @@ int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp)
     BWTS_TRY(exclusive_sum_u32(ctx, chunk_sum, chunks * 256, scan_temp));
     radix_chunk_apply_kernel<<<dim3((unsigned)chunks), dim3(256), 0, ctx->stream>>>(tile_hist, tiles, chunks, chunk_sum);
     HIPC(hipGetLastError());
+    return BWTS_OK;
+}
+
+// Stable sort of bare u64 keys on bits [lo_bit, lo_bit + bits): 16 bytes per element and pass.  Product tile shape only.
+// Returns in *result_buf which of keys[] holds the output.
+int radix_sort_keys(bwts_ctx *ctx, u64 *keys[2], u32 *tile_hist, void *scan_temp, u64 m, int lo_bit, int bits, int *result_buf)
+{
+    int cur = 0;
+    const u64 tiles = (m + 8191) / 8192;
+    constexpr size_t lds = (size_t)512 * 16 * 9 + 2048 + 64 + (size_t)8 * 512;
+    BWTS_TRY(ensure_dyn_lds(ctx, (const void *)radix_scatter2_kernel<512, 16, 4, false, false, true>, lds));
+    for (int shift = lo_bit; shift < lo_bit + bits; shift += 8) {
+        {
+            SpanGuard g(ctx, BWTS_K_RADIX_HIST, m, 8 * m);
+            launch_hist_t<512, 16>(ctx, tiles, keys[cur], m, shift, tile_hist);
+        }
+        {
+            SpanGuard g(ctx, BWTS_K_RADIX_SCAN, tiles * 256, tiles * 256 * 12);
+            BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, scan_temp));
+        }
+        SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 16 * m);
+        radix_scatter2_kernel<512, 16, 4, false, false, true><<<dim3((unsigned)rx_grid(tiles)), dim3(512), lds, ctx->stream>>>(
+            keys[cur], nullptr, keys[cur ^ 1], nullptr, tile_hist, m, shift, nullptr, nullptr);
+        HIPC(hipGetLastError());
+        cur ^= 1;
+    }
+    *result_buf = cur;
     return BWTS_OK;
 }
 

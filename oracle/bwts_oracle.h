@@ -34,8 +34,12 @@ int oracle_suffix_array(const uint8_t *T, int32_t *SA, int64_t n);
 
 /* Forward BWTS following the reference pipeline: SA -> ISA -> Lyndon factors as
  * prefix minima of ISA -> sequential cyclic fix-up -> emission
- * (mk_bwts_sa.c:114-195 and :74-112).  out has n bytes.  n < 2^31. */
+ * (mk_bwts_sa.c:114-195 and :74-112).  out has n bytes. */
 int oracle_forward(const uint8_t *T, int64_t n, uint8_t *out);
+
+/* The same pipeline compiled with 64-bit indices (what oracle_forward uses from 2^31 - 1 bytes on, beyond the
+ * reference's int/saidx_t range); callable on any n so that tests can hold it against the 32-bit instance. */
+int oracle_forward64(const uint8_t *T, int64_t n, uint8_t *out);
 
 /* Same, also returning per-phase wall seconds in the five MARK_TIME slots of
  * mk_bwts_sa.c:50,124,168,190 (suffix sort, ISA, fix, generate). */

@@ -24,6 +24,8 @@ def lib():
         u8p = ctypes.c_void_p
         L.oracle_forward.argtypes = [u8p, ctypes.c_int64, u8p]
         L.oracle_forward.restype = ctypes.c_int
+        L.oracle_forward64.argtypes = [u8p, ctypes.c_int64, u8p]
+        L.oracle_forward64.restype = ctypes.c_int
         L.oracle_forward_timed.argtypes = [u8p, ctypes.c_int64, u8p, ctypes.POINTER(ctypes.c_double)]
         L.oracle_forward_timed.restype = ctypes.c_int
         L.oracle_forward_def.argtypes = [u8p, ctypes.c_int64, u8p]
@@ -56,6 +58,11 @@ def _call(fn, data):
 
 def forward(data):
     return _call(lib().oracle_forward, data)
+
+
+def forward64(data):
+    """The pipeline's 64-bit-index instance (what forward() switches to from 2^31 - 1 bytes on)."""
+    return _call(lib().oracle_forward64, data)
 
 
 def forward_def(data):

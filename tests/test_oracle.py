@@ -129,6 +129,17 @@ def test_definition_vs_pipeline_random():
             assert np.array_equal(O.forward(O.inverse(x)), x)   # any bytes are a valid inverse input
 
 
+def test_64bit_index_instance_equals_32bit():
+    """oracle_forward switches to 64-bit indices above the reference's range; the same code on small inputs must give the
+    pinned 32-bit instance's bytes (this is what makes the golden above 2^31 in tests/golden/big_forward.json an oracle result)."""
+    rng = np.random.default_rng(17)
+    for x in ADVERSARIAL + [rng.integers(0, s, size=int(rng.integers(1, 3000)), dtype=np.uint8).tobytes() for s in (1, 2, 4, 256) for _ in range(10)]:
+        assert np.array_equal(O.forward64(x), O.forward(x))
+    for kind in ("zipf", "dna", "text"):
+        x = O.generate(kind, 300001, 6)
+        assert np.array_equal(O.forward64(x), O.forward(x))
+
+
 def test_adversarial():
     for x in ADVERSARIAL:
         a, b = O.forward(x), O.forward_def(x)

@@ -1,6 +1,9 @@
 #!/bin/bash
 # usage: tools/gpu_call.sh <timeout_s> <session script>   -- runs the script on a GPU box; waits while the pool has no free box (exit 3)
 T=$1; S=$2
+# what travels is what is built: never send sources newer than the library
+make -s -C "$(dirname "$0")/../bijective-bwt_amd" -j8 all >/dev/null || { echo 'build failed'; exit 1; }
+make -s -C "$(dirname "$0")/../oracle" all >/dev/null || { echo 'oracle build failed'; exit 1; }
 for try in $(seq 1 40); do
   /usr/local/graft/bin/gpurun --timeout $T -- "bash $S"
   rc=$?
