@@ -160,7 +160,9 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
     for (int i = 0; i < STAGE_SLOTS; i++) {
         if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
         if (ctx->slot_ev[i]) (void)hipEventDestroy(ctx->slot_ev[i]);
+        if (ctx->slot_ev2[i]) (void)hipEventDestroy(ctx->slot_ev2[i]);
     }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (int i = 0; i < 2; i++) if (ctx->d_io[i]) (void)hipFree(ctx->d_io[i]);
     for (const auto &b : ctx->host_blocks) (void)hipHostFree(b.first);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -211,6 +213,14 @@ extern "C" int bwts_inverse_device(bwts_ctx *ctx, const void *d_in, uint64_t n, 
 
 void CopyPool::part(int i)
 {
+    if (touching) {                   // workers 1 .. parts-1 share the buffer; the caller takes no part
+        const int nw = parts - 1;
+        const size_t per = ((len / (size_t)nw) + 4095) & ~(size_t)4095;
+        const size_t lo = per * (size_t)(i - 1) < len ? per * (size_t)(i - 1) : len;
+        const size_t hi = i == nw ? len : (lo + per < len ? lo + per : len);
+        for (size_t o = lo; o < hi; o += 4096) ((volatile char *)dst)[o] = 0;
+        return;
+    }
     // page-aligned cuts: two workers never fault on the same page of a fresh destination
     const size_t per = ((len / (size_t)parts) + 4095) & ~(size_t)4095;
     const size_t lo = per * (size_t)i < len ? per * (size_t)i : len;
@@ -254,6 +264,26 @@ void CopyPool::copy(void *d, const void *s_, size_t n)
     part(0);
     std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [&] { return pending == 0; });
+}
+
+void CopyPool::touch_async(void *d, size_t n)
+{
+    if (parts == 1 || n < ((size_t)4 << 20)) return;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        dst = (char *)d; src = nullptr; len = n;
+        touching = true;
+        pending = parts - 1;
+        generation++;
+    }
+    cv_work.notify_all();
+}
+
+void CopyPool::wait()
+{
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+    touching = false;
 }
 
 void CopyPool::shutdown()
@@ -310,7 +340,9 @@ static int ensure_staging(bwts_ctx *ctx)
             ctx->pinned[i] = (char *)p;
         }
         if (!ctx->slot_ev[i]) HIPC(hipEventCreateWithFlags(&ctx->slot_ev[i], hipEventDisableTiming));
+        if (!ctx->slot_ev2[i]) HIPC(hipEventCreateWithFlags(&ctx->slot_ev2[i], hipEventDisableTiming));
     }
+    if (!ctx->copy_stream) HIPC(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     ctx->pinned_cap = STAGE_CHUNK;
     if (!ctx->pool) {
         int threads = 6;                                   // BWTS_COPY_THREADS: 1 = the calling thread alone
@@ -366,13 +398,20 @@ static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n, bwts_sin
         return BWTS_OK;
     }
     BWTS_TRY(ensure_staging(ctx));
+    // a chunk's first part is moved by the copy kernel, the rest by the DMA engine on the second queue: the two paths
+    // add up on the link (BWTS_D2H_SPLIT = percent moved by the kernel)
+    static const int kernel_pct = [] { const char *e = getenv("BWTS_D2H_SPLIT"); int v = e ? atoi(e) : 100; return v < 0 ? 0 : v > 100 ? 100 : v; }();
     const u64 chunks = (n + STAGE_CHUNK - 1) / STAGE_CHUNK;
     auto issue = [&](u64 c) -> int {
         const u64 off = c * STAGE_CHUNK;
         const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
         const int slot = (int)(c % STAGE_SLOTS);
-        BWTS_TRY(pcie_copy(ctx, ctx->pinned[slot], d_src + off, len, by_kernel, hipMemcpyDeviceToHost));
+        size_t klen = by_kernel ? (len * (size_t)kernel_pct / 100) & ~(size_t)4095 : 0;
+        if (by_kernel && kernel_pct == 100) klen = len;
+        if (klen) BWTS_TRY(pcie_copy(ctx, ctx->pinned[slot], d_src + off, klen, true, hipMemcpyDeviceToHost));
         HIPC(hipEventRecord(ctx->slot_ev[slot], ctx->stream));
+        if (klen < len) HIPC(hipMemcpyAsync(ctx->pinned[slot] + klen, d_src + off + klen, len - klen, hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPC(hipEventRecord(ctx->slot_ev2[slot], ctx->copy_stream));
         return BWTS_OK;
     };
     for (u64 c = 0; c < chunks && c < STAGE_SLOTS; c++) BWTS_TRY(issue(c));
@@ -381,11 +420,12 @@ static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n, bwts_sin
         const u64 off = c * STAGE_CHUNK;
         const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
         const int slot = (int)(c % STAGE_SLOTS);
-        if (hipEventSynchronize(ctx->slot_ev[slot]) != hipSuccess) { rc = BWTS_E_HIP; break; }
+        if (hipEventSynchronize(ctx->slot_ev[slot]) != hipSuccess || hipEventSynchronize(ctx->slot_ev2[slot]) != hipSuccess) { rc = BWTS_E_HIP; break; }
         if (sink) { if (sink(user, (const uint8_t *)ctx->pinned[slot], len) != 0) { rc = BWTS_E_SINK; break; } }
         else ctx->pool->copy(h_dst + off, ctx->pinned[slot], len);
         if (c + STAGE_SLOTS < chunks && (rc = issue(c + STAGE_SLOTS)) != BWTS_OK) break;
     }
+    if (hipStreamSynchronize(ctx->copy_stream) != hipSuccess && rc == BWTS_OK) rc = BWTS_E_HIP;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == BWTS_OK) rc = BWTS_E_HIP;
     return rc;
 }
@@ -420,7 +460,12 @@ static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_
     double t0 = wall_ms();
     BWTS_TRY(staged_h2d(ctx, ctx->d_io[0], in, n));
     const double h2d = wall_ms() - t0;
-    BWTS_TRY(run_device(ctx, fn, ctx->d_io[0], n, ctx->d_io[1]));
+    // the caller's output buffer is usually fresh: its page faults are taken by the copy workers during the transform
+    const bool touch = !sink && !is_pinned_block(ctx, out, n) && ensure_staging(ctx) == BWTS_OK;
+    if (touch) ctx->pool->touch_async(out, n);
+    const int rcd = run_device(ctx, fn, ctx->d_io[0], n, ctx->d_io[1]);
+    if (touch) ctx->pool->wait();
+    BWTS_TRY(rcd);
     t0 = wall_ms();
     const int rc = staged_d2h(ctx, out, ctx->d_io[1], n, sink, user);
     ctx->tm.d2h_ms = wall_ms() - t0;

@@ -43,6 +43,7 @@ struct Alphabet {
     int hstep;      // symbols every key is guaranteed to cover: the step of round 1 (msym, or key_bits / longest code)
     int patch_span; // positions in front of a factor's end whose key wraps around (msym - 1, or 64)
 };
+#define SM_DGCNT  2816      // 8 + 1024 words: counters of the group-local dense rounds (dense_round_kernel)
 #define SM_SEGCNT 2560      // 256 words: large-group element counts of seg_small_sort_kernel (spread: one address would serialise)
 #define SM_VTAB 2048        // 256 words: (length << 32) | code of each byte value (variable-length codes)
 #define VL_MAXLEN 24        // longest code the variable-length key builder accepts
@@ -1347,6 +1348,8 @@ __global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restric
 #define DG_SPAN    (DG_THREADS * DG_ITEMS)            // list elements a workgroup looks at
 #define DG_OWN     (DG_SPAN - 2 * DG_CAP - 1)         // ... and decides: DG_CAP in front and DG_CAP + 1 behind are only looked at
 #define DG_FS_LDS  1024                  // factor starts kept in LDS when there are at most this many
+#define DG_CNT_BIG    8                 // counters[DG_CNT_BIG .. + DG_CNT_SPREAD): elements of larger groups, spread over many addresses
+#define DG_CNT_SPREAD 1024
 enum { DG_DONE = 0, DG_KEEP = 1, DG_BIG = 2, DG_MOVED = 4 };      // state: low bits = what happens to the element; DG_MOVED: its head (= rank) changed
 
 struct PrevSym {       // T[cprev(p)] (mk_bwts_sa.c:172-188): from the P array when one was built, else through the factor list
@@ -1360,12 +1363,104 @@ struct PrevSym {       // T[cprev(p)] (mk_bwts_sa.c:172-188): from the P array w
     }
 };
 
+// what a thread knows about its DG_ITEMS slots after the group detection shared by dense_round_kernel and dg_minpos_kernel
+struct DgSlots {
+    u32 idx[DG_ITEMS], gs[DG_ITEMS], sz[DG_ITEMS], h[DG_ITEMS];
+    u32 kind[DG_ITEMS];      // 0 nothing to do here, 1 member of a group handled here (slots gs .. gs + sz), 2 own element of a larger group
+};
+__device__ __forceinline__ void dg_detect(const u32 *__restrict__ idx, const u32 *__restrict__ head, u64 a, long long e0,
+                                          u32 *hd /* LDS, DG_SPAN */, u64 *startm /* LDS, DG_SPAN / 64 */, DgSlots &ds)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    bool valid[DG_ITEMS];
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const long long e = e0 + j * DG_THREADS + tid;
+        valid[j] = e >= 0 && (u64)e < a;
+        ds.h[j] = valid[j] ? head[e] : 0u;
+        hd[j * DG_THREADS + tid] = ds.h[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const u32 sl = (u32)j * DG_THREADS + tid;
+        const long long e = e0 + sl;
+        const bool prev_valid = e - 1 >= 0 && (u64)(e - 1) < a;
+        // slot 0 has no visible predecessor: it is never decided here, its flag only has to stop nobody (not a start)
+        const bool st = sl > 0 && (!valid[j] || !prev_valid || ds.h[j] != hd[sl - 1]);
+        const u64 m = __ballot(st);
+        if (lane == 0) startm[sl >> 6] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const u32 sl = (u32)j * DG_THREADS + tid;
+        ds.kind[j] = 0; ds.idx[j] = 0; ds.gs[j] = 0; ds.sz[j] = 0;
+        if (!valid[j]) continue;
+        // last start at or before sl, first start after sl: bit scans over at most two 64-slot words each
+        const u32 w = sl >> 6, b = sl & 63u;
+        const u64 cur = startm[w];
+        const u64 below = b == 63 ? cur : cur & ((2ull << b) - 1ull);
+        int gs = -1;
+        if (below) gs = (int)(w * 64 + 63 - (u32)__clzll((long long)below));
+        else if (w > 0) { const u64 pm = startm[w - 1]; if (pm) gs = (int)((w - 1) * 64 + 63 - (u32)__clzll((long long)pm)); }
+        const u64 above = b == 63 ? 0ull : cur >> (b + 1);
+        int ge = -1;
+        if (above) ge = (int)(sl + 1 + (u32)__ffsll((unsigned long long)above) - 1);
+        else if (w + 1 < DG_SPAN / 64) { const u64 nm = startm[w + 1]; if (nm) ge = (int)((w + 1) * 64 + (u32)__ffsll((unsigned long long)nm) - 1); }
+        const bool small = gs >= 1 && ge >= 0 && ge - gs <= DG_CAP;
+        if (small) {
+            if (gs >= DG_CAP && gs < DG_CAP + DG_OWN) { ds.kind[j] = 1; ds.gs[j] = (u32)gs; ds.sz[j] = (u32)(ge - gs); }
+        } else if (sl >= DG_CAP && sl < DG_CAP + DG_OWN) ds.kind[j] = 2;
+        if (ds.kind[j]) ds.idx[j] = idx[e0 + sl];
+    }
+}
+
+// Locality for the rounds that follow: the list is re-ordered once so that groups come in the order of their smallest
+// position.  The two copies of a repeated stretch tie position by position -- (p, q), (p + 1, q + 1), ... -- so consecutive
+// groups then touch consecutive ranks (gathers) and write consecutive ranks (updates) instead of random ones.  Sort key of an
+// element: its group's smallest position; larger groups go behind all of those, in their old order (n + head).
+__global__ __launch_bounds__(DG_THREADS) void dg_minpos_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, u64 a, u64 n, int kb,
+                                                               u64 *__restrict__ keys, u32 *__restrict__ vals)
+{
+    __shared__ u32 hd[DG_SPAN];
+    __shared__ u32 pos[DG_SPAN];
+    __shared__ u64 startm[DG_SPAN / 64];
+    const int tid = threadIdx.x;
+    const long long e0 = (long long)blockIdx.x * DG_OWN - DG_CAP;
+    DgSlots ds;
+    dg_detect(idx, head, a, e0, hd, startm, ds);
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++)
+        if (ds.kind[j] == 1) pos[j * DG_THREADS + tid] = ds.idx[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        if (!ds.kind[j]) continue;
+        const u64 e = (u64)(e0 + j * DG_THREADS + tid);
+        u64 sk;
+        if (ds.kind[j] == 1) {
+            u32 mn = 0xffffffffu;
+            for (u32 m = 0; m < ds.sz[j]; m++) { const u32 q = pos[ds.gs[j] + m]; mn = q < mn ? q : mn; }
+            sk = mn;
+        } else sk = n + (u64)ds.h[j];
+        keys[e] = ((u64)ds.h[j] << kb) | sk;
+        vals[e] = ds.idx[j];
+    }
+}
+__global__ __launch_bounds__(256) void dg_unpack_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 a, int kb,
+                                                        u32 *__restrict__ idx, u32 *__restrict__ head)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> kb); }
+}
+
 // Workgroup w looks at list elements [w * DG_OWN - DG_CAP, ... + DG_SPAN): LDS slot sl <-> element e = w * DG_OWN - DG_CAP + sl,
 // thread t holds slots t and t + DG_THREADS (consecutive lanes = consecutive slots, so a wave's group-start flags are one
 // __ballot).  It decides the elements of slots [DG_CAP, DG_CAP + DG_OWN): a group of at most DG_CAP members that starts
 // there is ordered here, whole (its members reach at most DG_CAP - 1 slots further, and the slot after them shows its end);
 // an element of that range whose group is larger is flagged DG_BIG.
-// counters: [1] elements of larger groups, [2] a group split.  rank[] is only read here: the new ranks are applied by the
+// counters: [2] a group split, [DG_CNT_BIG ...] elements of larger groups.  rank[] is only read here: the new ranks are applied by the
 // compaction pass at the end of the round (dg_compact_kernel) -- a round's keys must all come from the same version of the
 // ranks: a member that already shows its new rank next to a group-mate that still shows the old one would order the wrong way.
 template <bool CYCLIC>
@@ -1381,55 +1476,14 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
     __shared__ u64 startm[DG_SPAN / 64];     // bit = a group starts at this slot (an element outside the list counts as a start)
     __shared__ u32 fs[DG_FS_LDS];
     __shared__ u32 cnt_big, any_split;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const long long e0 = (long long)blockIdx.x * DG_OWN - DG_CAP;     // list element of slot 0
     if (tid == 0) { cnt_big = 0; any_split = 0; }
     const bool fs_lds = CYCLIC && k <= DG_FS_LDS;
     if (fs_lds) for (u32 i = tid; i < k; i += DG_THREADS) fs[i] = fstart[i];
-    bool valid[DG_ITEMS];
-    u32 myh[DG_ITEMS];
-#pragma unroll
-    for (int j = 0; j < DG_ITEMS; j++) {
-        const long long e = e0 + j * DG_THREADS + tid;
-        valid[j] = e >= 0 && (u64)e < a;
-        myh[j] = valid[j] ? head[e] : 0u;
-        hd[j * DG_THREADS + tid] = myh[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < DG_ITEMS; j++) {
-        const u32 sl = (u32)j * DG_THREADS + tid;
-        const long long e = e0 + sl;
-        const bool prev_valid = e - 1 >= 0 && (u64)(e - 1) < a;
-        // slot 0 has no visible predecessor: it is never decided here, its flag only has to stop nobody (not a start)
-        const bool st = sl > 0 && (!valid[j] || !prev_valid || myh[j] != hd[sl - 1]);
-        const u64 m = __ballot(st);
-        if (lane == 0) startm[sl >> 6] = m;
-    }
-    __syncthreads();
-    u32 my_idx[DG_ITEMS], my_gs[DG_ITEMS], my_sz[DG_ITEMS], my_kind[DG_ITEMS];   // kind: 0 nothing to do here, 1 member of a group ordered here, 2 own element of a larger group
-#pragma unroll
-    for (int j = 0; j < DG_ITEMS; j++) {
-        const u32 sl = (u32)j * DG_THREADS + tid;
-        my_kind[j] = 0; my_idx[j] = 0; my_gs[j] = 0; my_sz[j] = 0;
-        if (!valid[j]) continue;
-        // last start at or before sl, first start after sl: bit scans over at most two 64-slot words each
-        const u32 w = sl >> 6, b = sl & 63u;
-        const u64 cur = startm[w];
-        const u64 below = b == 63 ? cur : cur & ((2ull << b) - 1ull);
-        int gs = -1;
-        if (below) gs = (int)(w * 64 + 63 - (u32)__clzll((long long)below));
-        else if (w > 0) { const u64 pm = startm[w - 1]; if (pm) gs = (int)((w - 1) * 64 + 63 - (u32)__clzll((long long)pm)); }
-        const u64 above = b == 63 ? 0ull : cur >> (b + 1);
-        int ge = -1;
-        if (above) ge = (int)(sl + 1 + (u32)__ffsll((unsigned long long)above) - 1);
-        else if (w + 1 < DG_SPAN / 64) { const u64 nm = startm[w + 1]; if (nm) ge = (int)((w + 1) * 64 + (u32)__ffsll((unsigned long long)nm) - 1); }
-        const bool small = gs >= 1 && ge >= 0 && ge - gs <= DG_CAP;
-        if (small) {
-            if (gs >= DG_CAP && gs < DG_CAP + DG_OWN) { my_kind[j] = 1; my_gs[j] = (u32)gs; my_sz[j] = (u32)(ge - gs); }
-        } else if (sl >= DG_CAP && sl < DG_CAP + DG_OWN) my_kind[j] = 2;
-        if (my_kind[j]) my_idx[j] = idx[e0 + sl];
-    }
+    DgSlots ds;
+    dg_detect(idx, head, a, e0, hd, startm, ds);
+    u32 (&my_idx)[DG_ITEMS] = ds.idx, (&my_gs)[DG_ITEMS] = ds.gs, (&my_sz)[DG_ITEMS] = ds.sz, (&my_kind)[DG_ITEMS] = ds.kind, (&myh)[DG_ITEMS] = ds.h;
     // successor ranks of the members ordered here
     u32 my_key[DG_ITEMS];
 #pragma unroll
@@ -1491,7 +1545,8 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
     if (split_here) any_split = 1;
     __syncthreads();
     if (tid == 0) {
-        if (cnt_big) atomicAdd(&counters[1], (unsigned long long)cnt_big);
+        // (one shared counter cost ~75 ns per workgroup: device-scope atomics on one address serialise across the XCDs)
+        if (cnt_big) atomicAdd(&counters[DG_CNT_BIG + (blockIdx.x & (DG_CNT_SPREAD - 1))], (unsigned long long)cnt_big);
         if (any_split && __hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
             __hip_atomic_store(&counters[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1676,7 +1731,7 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                         ActiveList cur, u64 a, u32 *SA, bool need_sa, u32 *rounds_io)
 {
     if (a > 0xffffffffull) return BWTS_E_NOMEM;     // every position tied at n = 2^32: beyond what the side buffers hold
-    u64 *cnt = ctx->d_small + SM_COUNTERS;
+    u64 *cnt = ctx->d_small + SM_DGCNT;
     const size_t e4 = align_up((size_t)a * 4, 256), e1 = align_up((size_t)a, 256);
     char *base = nullptr;
     BWTS_TRY(aux_reserve(ctx, 6 * e4 + e1, &base));
@@ -1693,9 +1748,35 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u8 *out = CYCLIC ? sp.carry_out : nullptr;
     u32 rounds = *rounds_io;
     int nxt = 0;
+    static const bool reorder_ok = [] { const char *e = getenv("BWTS_DENSE_ORDER"); return !(e && atoi(e) == 0); }();
+    const int kb = bitlen_u64(2 * n - 1);
+    if (reorder_ok && kb <= 32 && a >= (1ull << 16)) {
+        // groups in the order of their smallest position (see dg_minpos_kernel); the sorted list lands in sets[0]
+        char *ob = nullptr;
+        const size_t a8 = align_up((size_t)a * 8, 256);
+        BWTS_TRY(aux_reserve_slot(ctx, 1, 2 * a8 + 2 * e4, &ob));
+        SortPlan op;
+        op.keys[0] = (u64 *)ob; op.keys[1] = (u64 *)(ob + a8);
+        op.vals[0] = (u32 *)(ob + 2 * a8); op.vals[1] = (u32 *)(ob + 2 * a8 + e4);
+        op.tile_hist = sp.tile_hist; op.scan_temp = sp.scan_temp;
+        {
+            SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
+            dg_minpos_kernel<<<dim3((unsigned)((a + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a, n, kb, op.keys[0], op.vals[0]);
+            HIPC(hipGetLastError());
+        }
+        int ores = 0;
+        BWTS_TRY(radix_sort_pairs(ctx, op, a, kb, &ores));
+        {
+            SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
+            dg_unpack_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(op.keys[ores], op.vals[ores], a, kb, sets[0].idx, sets[0].head);
+            HIPC(hipGetLastError());
+        }
+        cur = sets[0];
+        nxt = 1;
+    }
     for (u64 h = (u64)al.hstep;; h <<= 1) {
         rounds++;
-        HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
+        HIPC(hipMemsetAsync(cnt, 0, (DG_CNT_BIG + DG_CNT_SPREAD) * sizeof(u64), ctx->stream));
         {
             SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 29 * a);       // idx, head in; idx, head, state out; one rank gather
             const unsigned blocks = (unsigned)((a + DG_OWN - 1) / DG_OWN);
@@ -1703,8 +1784,9 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 cur.idx, cur.head, a, sp.rank, n, h, d_fstart, k, t_idx, t_head, state, prev, out, (unsigned long long *)cnt);
             HIPC(hipGetLastError());
         }
-        BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
-        const u64 m_big = ctx->h_small[SM_COUNTERS + 1];
+        BWTS_TRY(read_small(ctx, SM_DGCNT, DG_CNT_BIG + DG_CNT_SPREAD));
+        u64 m_big = 0;
+        for (int c = 0; c < DG_CNT_SPREAD; c++) m_big += ctx->h_small[SM_DGCNT + DG_CNT_BIG + c];
         if (m_big > a) return BWTS_E_INTERNAL;
         if (m_big) {
             // larger groups: compact (with the successor ranks), radix sort by (group ordinal, successor rank), regroup, put back
@@ -1745,9 +1827,9 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                                                                                           sets[nxt].head, cnt + 0);
             HIPC(hipGetLastError());
         }
-        BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
-        const u64 a_new = ctx->h_small[SM_COUNTERS + 0];
-        const u64 splits = ctx->h_small[SM_COUNTERS + 2];
+        BWTS_TRY(read_small(ctx, SM_DGCNT, 4));
+        const u64 a_new = ctx->h_small[SM_DGCNT + 0];
+        const u64 splits = ctx->h_small[SM_DGCNT + 2];
         if (a_new > a) return BWTS_E_INTERNAL;
         cur = sets[nxt];
         nxt ^= 1;

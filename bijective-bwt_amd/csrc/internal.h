@@ -35,8 +35,13 @@ struct CopyPool {
     const char *src = nullptr;
     size_t len = 0;
     int parts = 1;
+    bool touching = false;  // the current job writes one byte per page of dst instead of copying
     void start(int threads);
     void copy(void *dst, const void *src, size_t len);      // returns when all parts are done
+    // The workers alone fault in the pages of a fresh buffer (one zero byte per 4 KiB) while the caller goes on: the
+    // first-touch faults of a caller's output buffer are paid while the GPU transforms.  wait() before the next job.
+    void touch_async(void *dst, size_t len);
+    void wait();
     void shutdown();
     void part(int i);
 };
@@ -62,7 +67,8 @@ struct bwts_ctx {
     // host-buffer entry points: pinned staging ring with one event per slot, copy workers, device-side in/out buffers
     // that stay with the context, and the pinned blocks handed out by bwts_host_alloc
     char  *pinned[STAGE_SLOTS];
-    hipEvent_t slot_ev[STAGE_SLOTS];
+    hipEvent_t slot_ev[STAGE_SLOTS], slot_ev2[STAGE_SLOTS];
+    hipStream_t copy_stream;        // second queue: part of a device-to-host chunk goes through the DMA engine while a kernel moves the rest
     size_t pinned_cap;
     CopyPool *pool;
     u8    *d_io[2];

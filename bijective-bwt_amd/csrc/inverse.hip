@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void lr2_distribute_kernel(const uint4 *__rest
 // An unreached element follows its own cycle until it meets a smaller element (not the cycle's minimum: done) or
 // returns to itself (it is the minimum: it appends the cycle's record).  `cap` bounds the steps of one lane.
 __global__ __launch_bounds__(256) void tiny_cycle_scan_kernel(const u32 *__restrict__ uidx, const u32 *__restrict__ ulf, u64 nu,
-                                                              const u32 *__restrict__ LF, u32 cap, CycleRec *__restrict__ recs,
+                                                              const u32 *__restrict__ LF, u32 cap, uint2 *__restrict__ tiny /* x smallest element, y length */,
                                                               unsigned long long *__restrict__ count, unsigned long long *__restrict__ overflow)
 {
     const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -673,48 +673,49 @@ __global__ __launch_bounds__(256) void tiny_cycle_scan_kernel(const u32 *__restr
     unsigned long long b = 0;
     if (lane_id() == leader) b = atomicAdd(count, (unsigned long long)__popcll(m));
     b = shfl_t((u64)b, leader);
-    if (ismin) {
-        CycleRec c; c.leader = LR_NIL; c.minelem = x; c.len = len; c.pad = 0;
-        recs[b + (u64)__popcll(m & lanemask_lt())] = c;
-    }
+    if (ismin) tiny[b + (u64)__popcll(m & lanemask_lt())] = make_uint2(x, len);
 }
 
 // ---- cycle order: by smallest element, the cycle holding index 0 ends the text (unbwts.c:62-77) ------------------------
-__global__ __launch_bounds__(256) void cycle_keys_kernel(const CycleRec *__restrict__ recs, u64 m, u64 *__restrict__ keys, u32 *__restrict__ vals)
+// record i of the combined list: a cycle without a splitter (i < kt) or a cycle of the reduced list
+struct CycleList {
+    const uint2 *tiny; u64 kt; const CycleRec *recs; u64 kc;
+    __device__ __forceinline__ u32 minelem(u64 i) const { return i < kt ? tiny[i].x : recs[i - kt].minelem; }
+    __device__ __forceinline__ u32 len(u64 i) const { return i < kt ? tiny[i].y : recs[i - kt].len; }
+};
+__global__ __launch_bounds__(256) void cycle_keys_kernel(CycleList cl, u64 *__restrict__ keys, u32 *__restrict__ vals)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < m) { keys[i] = recs[i].minelem; vals[i] = (u32)i; }
+    if (i < cl.kt + cl.kc) { keys[i] = cl.minelem(i); vals[i] = (u32)i; }
 }
 struct CycleLenIn {
-    const CycleRec *recs; const u32 *order;
-    __device__ __forceinline__ u32 operator()(u64 j) const { return recs[order[j]].len; }
+    CycleList cl; const u32 *order;
+    __device__ __forceinline__ u32 operator()(u64 j) const { return cl.len(order[j]); }
 };
 struct CycleEndOut {
-    const CycleRec *recs; const u32 *order; u64 m; u32 last; u32 *end_by_leader; u32 *end_of_rec; u64 *total;
+    CycleList cl; const u32 *order; u32 last; u32 *end_by_leader; u32 *end_of_tiny; u64 *total;
     __device__ __forceinline__ void operator()(u64 j, u32 used) const
     {
         const u32 i = order[j];
-        const CycleRec c = recs[i];
         const u32 end = last - used;                    // n - 1 - (elements of the cycles ordered before this one)
-        if (c.leader != LR_NIL) end_by_leader[c.leader] = end;
-        end_of_rec[i] = end;
-        if (j + 1 == m) *total = (u64)used + c.len;     // == n (mod 2^32 for n = 2^32)
+        if (i < cl.kt) end_of_tiny[i] = end;
+        else end_by_leader[cl.recs[i - cl.kt].leader] = end;
+        if (j + 1 == cl.kt + cl.kc) *total = (u64)used + cl.len(i);     // == n (mod 2^32 for n = 2^32)
     }
 };
 
 // out[end - t] = B[LF^t(min)] for a cycle without a splitter: unbwts.c:73-82, one lane per cycle
-__global__ __launch_bounds__(256) void tiny_place_kernel(const CycleRec *__restrict__ recs, u64 m, const u32 *__restrict__ end_of_rec,
+__global__ __launch_bounds__(256) void tiny_place_kernel(const uint2 *__restrict__ tiny, u64 kt, const u32 *__restrict__ end_of_tiny,
                                                          const u32 *__restrict__ LF, const u64 *__restrict__ Cg, u8 *__restrict__ out)
 {
     __shared__ u64 Ctab[257];
     for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
     __syncthreads();
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    const CycleRec c = recs[i];
-    if (c.leader != LR_NIL) return;
-    u32 x = c.minelem, pos = end_of_rec[i];
-    for (u32 t = 0; t < c.len; t++) {
+    if (i >= kt) return;
+    const uint2 c = tiny[i];
+    u32 x = c.x, pos = end_of_tiny[i];
+    for (u32 t = 0; t < c.y; t++) {
         const u32 y = LF[x];
         out[pos--] = (u8)symbol_of(Ctab, y);
         x = y;
@@ -858,16 +859,16 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     // elements in cycles without a splitter: collected into lists sized by their number (a second pass if the first room is too small)
     size_t ucap = ctx->unv_hint > UNV_CAP0 ? ctx->unv_hint : UNV_CAP0;
     if (ucap > n) ucap = (size_t)n;
-    u32 *uidx = nullptr, *ulf = nullptr, *end_of_rec = nullptr;
-    CycleRec *recs = nullptr;
+    u32 *uidx = nullptr, *ulf = nullptr, *end_of_tiny = nullptr;
+    uint2 *tiny = nullptr;
     auto lay_out_lists = [&](size_t cap) -> int {
-        // uidx, ulf: cap entries; cycle records and their ends: (cycles of the reduced list <= l2cap) + cap
+        // uidx, ulf: cap entries; records of the cycles without a splitter and their ends: at most cap
         char *ub = nullptr;
-        const size_t e4 = align_up(cap * 4, 256), r16 = align_up((l2cap + cap) * sizeof(CycleRec), 256), r4 = align_up((l2cap + cap) * 4, 256);
-        BWTS_TRY(aux_reserve_slot(ctx, 0, 2 * e4 + r16 + r4, &ub));
+        const size_t e4 = align_up(cap * 4, 256), e8 = align_up(cap * 8, 256);
+        BWTS_TRY(aux_reserve_slot(ctx, 0, 3 * e4 + e8, &ub));
         uidx = (u32 *)ub; ulf = (u32 *)(ub + e4);
-        recs = (CycleRec *)(ub + 2 * e4);
-        end_of_rec = (u32 *)(ub + 2 * e4 + r16);
+        tiny = (uint2 *)(ub + 2 * e4);
+        end_of_tiny = (u32 *)(ub + 2 * e4 + e8);
         return BWTS_OK;
     };
     BWTS_TRY(lay_out_lists(ucap));
@@ -942,7 +943,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         if (cap > 64 * G) cap = 64 * G;
         if (cap < 4 * G) cap = 4 * G;
         tiny_cycle_scan_kernel<<<dim3(grid1(nu)), dim3(256), 0, ctx->stream>>>(uidx, ulf, nu, LF, (u32)(cap > 0xfffffff0ull ? 0xfffffff0ull : cap),
-                                                                              recs, ticket + 7, ticket + 4);
+                                                                              tiny, ticket + 7, ticket + 4);
         HIPC(hipGetLastError());
     }
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
@@ -956,7 +957,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     // order the cycles by smallest element on the device: sort (minelem, record), prefix sums of the lengths
     {
         SpanGuard sg(ctx, BWTS_K_LISTRANK, kall, 0);
-        HIPC(hipMemcpyAsync(recs + kt, d_recs2, kc * sizeof(CycleRec), hipMemcpyDeviceToDevice, ctx->stream));
+        const CycleList cl{tiny, kt, d_recs2, kc};
         char *sb = nullptr;
         const size_t k8 = align_up(kall * 8, 256), k4 = align_up(kall * 4, 256);
         BWTS_TRY(aux_reserve_slot(ctx, 1, 2 * k8 + 2 * k4 + radix_tile_hist_bytes(kall) + scan_temp_bytes(kall) + 4096, &sb));
@@ -965,12 +966,12 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         cp.vals[0] = (u32 *)(sb + 2 * k8); cp.vals[1] = (u32 *)(sb + 2 * k8 + k4);
         cp.tile_hist = (u32 *)(sb + 2 * k8 + 2 * k4);
         cp.scan_temp = sb + 2 * k8 + 2 * k4 + radix_tile_hist_bytes(kall);
-        cycle_keys_kernel<<<dim3(grid1(kall)), dim3(256), 0, ctx->stream>>>(recs, kall, cp.keys[0], cp.vals[0]);
+        cycle_keys_kernel<<<dim3(grid1(kall)), dim3(256), 0, ctx->stream>>>(cl, cp.keys[0], cp.vals[0]);
         int res = 0;
         int kbits = 0; for (u64 x = n - 1; x; x >>= 1) kbits++;
         BWTS_TRY(radix_sort_pairs(ctx, cp, kall, kbits < 1 ? 1 : kbits, &res));
-        CycleLenIn lin{recs, cp.vals[res]};
-        CycleEndOut lout{recs, cp.vals[res], kall, (u32)(n - 1), end_by_leader, end_of_rec, ctx->d_small + SMI_COUNTERS + 13};
+        CycleLenIn lin{cl, cp.vals[res]};
+        CycleEndOut lout{cl, cp.vals[res], (u32)(n - 1), end_by_leader, end_of_tiny, ctx->d_small + SMI_COUNTERS + 13};
         BWTS_TRY((device_scan<false, u32>(ctx, kall, lin, lout, OpAdd(), 0u, cp.scan_temp)));
         lr_place2_kernel<<<dim3(grid1(s2all)), dim3(256), 0, ctx->stream>>>(s2all, lrmin[cur], lrsum[sc], dist, min_dist, end_by_leader, place2);
         lr2_distribute_kernel<<<dim3(grid1(s2all)), dim3(256), 0, ctx->stream>>>(noderec, s2, s2all, U, place2, d_opos, d_wrap, d_clen);
@@ -986,7 +987,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         const u64 threads = s_all << tpn_log2;
         place_segments_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(seg, s_all, slot, tpn_log2, noderec,
                                                                                                       d_opos, d_wrap, d_clen, d_out);
-        if (kt) tiny_place_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(recs, kt, end_of_rec, LF, dC, d_out);
+        if (kt) tiny_place_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(tiny, kt, end_of_tiny, LF, dC, d_out);
         HIPC(hipGetLastError());
     }
     BWTS_TRY(read_small(ctx, SMI_COUNTERS + 13, 1));
