@@ -284,13 +284,26 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
                         const double partners = m >= 8.0 ? (double)n * m / pairs : (double)n * share[b];   // few hits: trust the model
                         if (1.0 - exp(-partners) <= 1.0 / 64.0) { kb_emp = b; break; }
                     }
+                    bool long_repeats = false;
+                    if (kb_emp == 64) {
+                        // No width gets the ties down.  Short repeats (words) thin out steadily as the key grows and want the
+                        // full 64 bits; long repeats (copied stretches) tie their positions at every width alike -- the sample's
+                        // matches stop falling -- and then every key byte beyond that point is a radix pass spent on nothing.
+                        const double m56 = (double)ctx->h_small[CNT_SAMPLE + 4];
+                        for (int b = 32, w = 1; b <= 48; b += 8, w++) {
+                            const double m = (double)ctx->h_small[CNT_SAMPLE + w];
+                            if (m56 >= 8.0 && m <= 1.25 * m56 + 8.0) { kb_emp = b; long_repeats = true; break; }
+                        }
+                    }
                     if (kb_emp > kb) {
                         kb = kb_emp;
-                        // the fixed-width alternative was sized by the same model: let it use every symbol that fits
-                        al->msym = 64 / bits;
-                        al->key_bits = al->bits * al->msym;
-                        al->hstep = al->msym;
-                        al->patch_span = al->msym - 1;
+                        if (!long_repeats) {
+                            // the fixed-width alternative was sized by the same model: let it use every symbol that fits
+                            al->msym = 64 / bits;
+                            al->key_bits = al->bits * al->msym;
+                            al->hstep = al->msym;
+                            al->patch_span = al->msym - 1;
+                        }
                     }
                 }
             }
@@ -1211,14 +1224,19 @@ __global__ __launch_bounds__(256) void rank_keys_kernel(const u32 *__restrict__ 
         }
     }
 }
-__global__ __launch_bounds__(256) void rank_apply_kernel(const u64 *__restrict__ keys, u64 n, u32 *__restrict__ rank)
+// The positions are a permutation, so after the sort window w (positions [w << wlog, (w + 1) << wlog)) occupies exactly the
+// keys [w << wlog, ...): one workgroup takes one window, scatters the heads into an LDS image of the window's ranks and
+// writes the image out whole -- a streaming kernel (20 ms -> 3.5 ms at n = 2^30 against scattering to memory, where the four
+// workgroups sharing a window sat on different XCDs and every rank line left their L2s in pieces).
+#define RA_WLOG_MAX 14
+__global__ __launch_bounds__(1024) void rank_apply_kernel(const u64 *__restrict__ keys, u64 n, int wlog, u32 *__restrict__ rank)
 {
-    // consecutive keys -> consecutive windows: a workgroup's writes stay inside a few hundred KB
-    const u64 per = 4096;
-    for (u64 base = (u64)blockIdx.x * per; base < n; base += (u64)gridDim.x * per) {
-        const u64 end = base + per < n ? base + per : n;
-        for (u64 i = base + threadIdx.x; i < end; i += 256) { const u64 kv = keys[i]; rank[(u32)kv] = (u32)(kv >> 32); }
-    }
+    extern __shared__ __attribute__((aligned(16))) u32 ra_img[];
+    const u64 lo = (u64)blockIdx.x << wlog;
+    const u64 hi = lo + (1ull << wlog) < n ? lo + (1ull << wlog) : n;
+    for (u64 i = lo + threadIdx.x; i < hi; i += 1024) { const u64 kv = keys[i]; ra_img[(u32)kv - (u32)lo] = (u32)(kv >> 32); }
+    __syncthreads();
+    for (u64 i = lo + threadIdx.x; i < hi; i += 1024) rank[i] = ra_img[i - lo];
 }
 __global__ void count_tied_kernel(const u64 *__restrict__ keepw, const u64 *__restrict__ pre, u64 words, u64 *__restrict__ cnt_active)
 {
@@ -1444,7 +1462,7 @@ __global__ __launch_bounds__(DG_THREADS) void dg_minpos_kernel(const u32 *__rest
             for (u32 m = 0; m < ds.sz[j]; m++) { const u32 q = pos[ds.gs[j] + m]; mn = q < mn ? q : mn; }
             sk = mn;
         } else sk = n + (u64)ds.h[j];
-        keys[e] = ((u64)ds.h[j] << kb) | sk;
+        keys[e] = ((u64)ds.h[j] << 16) | (sk >> (kb - 16));        // kb >= 17 here (the list has at least 2^16 elements)
         vals[e] = ds.idx[j];
     }
 }
@@ -1452,7 +1470,7 @@ __global__ __launch_bounds__(256) void dg_unpack_kernel(const u64 *__restrict__ 
                                                         u32 *__restrict__ idx, u32 *__restrict__ head)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> kb); }
+    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> 16); }
 }
 
 // Workgroup w looks at list elements [w * DG_OWN - DG_CAP, ... + DG_SPAN): LDS slot sl <-> element e = w * DG_OWN - DG_CAP + sl,
@@ -1750,7 +1768,7 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     int nxt = 0;
     static const bool reorder_ok = [] { const char *e = getenv("BWTS_DENSE_ORDER"); return !(e && atoi(e) == 0); }();
     const int kb = bitlen_u64(2 * n - 1);
-    if (reorder_ok && kb <= 32 && a >= (1ull << 16)) {
+    if (reorder_ok && a >= (1ull << 16)) {
         // groups in the order of their smallest position (see dg_minpos_kernel); the sorted list lands in sets[0]
         char *ob = nullptr;
         const size_t a8 = align_up((size_t)a * 8, 256);
@@ -1764,8 +1782,10 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             dg_minpos_kernel<<<dim3((unsigned)((a + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a, n, kb, op.keys[0], op.vals[0]);
             HIPC(hipGetLastError());
         }
+        // the top 16 bits are what locality needs (groups whose smallest positions share a window of 2 n / 2^16 positions end
+        // up together, in their old relative order): two passes instead of four
         int ores = 0;
-        BWTS_TRY(radix_sort_pairs(ctx, op, a, kb, &ores));
+        BWTS_TRY(radix_sort_pairs(ctx, op, a, 16, &ores));
         {
             SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
             dg_unpack_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(op.keys[ores], op.vals[ores], a, kb, sets[0].idx, sets[0].head);
@@ -1938,11 +1958,14 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
             rank_keys_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(SA, n, flag_heads, flag_pre, rk[0]);
             HIPC(hipGetLastError());
+            // sorted on the position's top 16 bits (24 beyond n = 2^30): windows of at most 2^RA_WLOG_MAX positions
             const int pb = bitlen_u64(n - 1);
+            const int sbits = pb - 16 <= RA_WLOG_MAX ? 16 : 24;
             int rres = 0;
-            BWTS_TRY(radix_sort_keys(ctx, rk, sp.tile_hist, sp.scan_temp, n, pb - 16, 16, &rres));
-            blocks = (n + 4095) / 4096; if (blocks > 65536) blocks = 65536;
-            rank_apply_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(rk[rres], n, sp.rank);
+            BWTS_TRY(radix_sort_keys(ctx, rk, sp.tile_hist, sp.scan_temp, n, pb - sbits, sbits, &rres));
+            const int wlog = RA_WLOG_MAX;                   // sorted on at least the bits above 2^14: every 2^14 keys are 2^14 consecutive positions
+            BWTS_TRY(ensure_dyn_lds(ctx, (const void *)rank_apply_kernel, (size_t)4 << RA_WLOG_MAX));
+            rank_apply_kernel<<<dim3((unsigned)((n + (1ull << wlog) - 1) >> wlog)), dim3(1024), (size_t)4 << wlog, ctx->stream>>>(rk[rres], n, wlog, sp.rank);
             HIPC(hipGetLastError());
             rank_valid = true;
             rank_early = true;
