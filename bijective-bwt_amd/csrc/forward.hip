@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 // ------------------------------------------------------------------------------------
 // small-word layout in ctx->d_small / h_small (u64 words)
@@ -139,14 +140,18 @@ __global__ void count_prefix_matches_kernel(const u64 *keys, u32 samples, unsign
 // monotone-root bound, O(sigma^2).  Order-preserving means that comparing concatenated code words bit by bit is
 // comparing the symbol strings, so packed code bits sort like the text does -- but frequent symbols take fewer bits,
 // so a key of B bits separates positions about as well as B bits of entropy would.  Returns the longest code length.
-static int build_alphabetic_code(const u64 *hist, u64 n, u32 *code, u8 *len, double *avg_len, double *entropy)
+static int build_alphabetic_code(const u64 *hist, u64 n, u32 *code, u8 *len, double *avg_len, double *entropy, double smooth_scale = 1.0)
 {
-    static double C[256][256];
-    static u16 R[256][256];
+    // (heap, not static: contexts on different host threads may be here at the same time)
+    std::vector<double> Cv(256 * 256);
+    std::vector<u16> Rv(256 * 256);
+    double (*C)[256] = (double (*)[256])Cv.data();
+    u16 (*R)[256] = (u16 (*)[256])Rv.data();
     int sym[256], sigma = 0;
     double w[256], pre[257];
     for (int c = 0; c < 256; c++) { code[c] = 0; len[c] = 0; if (hist[c]) sym[sigma++] = c; }
-    const double smooth = (double)(n >> 14) + 1.0;          // keeps rare symbols' codes short enough for the key builder
+    // keeps rare symbols' codes short enough for the key builder; a larger scale flattens the tree (shorter longest code)
+    const double smooth = ((double)(n >> 14) + 1.0) * smooth_scale;
     pre[0] = 0;
     for (int i = 0; i < sigma; i++) { w[i] = (double)hist[sym[i]] + smooth; pre[i + 1] = pre[i] + w[i]; }
     if (sigma == 1) { len[sym[0]] = 1; *avg_len = 1; *entropy = 0; return 1; }
@@ -229,6 +234,7 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
         u32 vcode[256]; u8 vlen[256];
         double avg = 0, ent = 0;
         const int lmax = build_alphabetic_code(ctx->h_small + SM_HIST, n, vcode, vlen, &avg, &ent);
+        int lmax_eff = lmax;
         if (lmax <= VL_MAXLEN) {
             // Width: the smallest whole number of bytes B for which an i.i.d. source with this histogram leaves at most
             // ~0.8 % of the positions tied.  share[b] = probability that two independent positions agree on the first b
@@ -292,7 +298,26 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
                         const double m56 = (double)ctx->h_small[CNT_SAMPLE + 4];
                         for (int b = 32, w = 1; b <= 48; b += 8, w++) {
                             const double m = (double)ctx->h_small[CNT_SAMPLE + w];
-                            if (m56 >= 8.0 && m <= 1.25 * m56 + 8.0) { kb_emp = b; long_repeats = true; break; }
+                            if (m56 >= 8.0 && m <= 1.5 * m56 + 16.0) { kb_emp = b; long_repeats = true; break; }
+                        }
+                    }
+                    if (long_repeats) {
+                        // The rounds after round 0 will dominate, and their first step is the number of symbols EVERY key is
+                        // sure to cover (key bits / longest code word): a flatter tree -- longest code at most one bit above the
+                        // fixed width -- trades a little key entropy for a first step twice as long (one round less over
+                        // most of the input).
+                        double scale = 4.0;
+                        int lim = bits + 1 > 8 ? bits + 1 : 8;
+                        int l2 = lmax;
+                        u32 c2[256]; u8 n2[256];
+                        double avg2 = avg, ent2 = ent;
+                        while (l2 > lim && scale < 1e9) {
+                            l2 = build_alphabetic_code(ctx->h_small + SM_HIST, n, c2, n2, &avg2, &ent2, scale);
+                            scale *= 4.0;
+                        }
+                        if (l2 <= lim && l2 < lmax) {
+                            memcpy(vcode, c2, sizeof(c2)); memcpy(vlen, n2, sizeof(n2));
+                            lmax_eff = l2; avg = avg2;
                         }
                     }
                     if (kb_emp > kb) {
@@ -314,7 +339,7 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
             if ((vl && vl[0] == '1') || passes_var < passes_fixed || (passes_var == passes_fixed && avg < (double)bits - 0.25)) {
                 al->varlen = true;
                 al->key_bits = kb;
-                al->hstep = kb / lmax < 1 ? 1 : kb / lmax;
+                al->hstep = kb / lmax_eff < 1 ? 1 : kb / lmax_eff;
                 al->patch_span = 64;
                 al->msym = al->hstep;
                 u64 *tab = ctx->h_small + SM_VTAB;
@@ -1366,6 +1391,7 @@ __global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restric
 #define DG_SPAN    (DG_THREADS * DG_ITEMS)            // list elements a workgroup looks at
 #define DG_OWN     (DG_SPAN - 2 * DG_CAP - 1)         // ... and decides: DG_CAP in front and DG_CAP + 1 behind are only looked at
 #define DG_FS_LDS  1024                  // factor starts kept in LDS when there are at most this many
+#define DG_ORDER_BITS 24                // bits of a group's smallest position the list is ordered by (dg_minpos_kernel)
 #define DG_CNT_BIG    8                 // counters[DG_CNT_BIG .. + DG_CNT_SPREAD): elements of larger groups, spread over many addresses
 #define DG_CNT_SPREAD 1024
 enum { DG_DONE = 0, DG_KEEP = 1, DG_BIG = 2, DG_MOVED = 4 };      // state: low bits = what happens to the element; DG_MOVED: its head (= rank) changed
@@ -1462,7 +1488,7 @@ __global__ __launch_bounds__(DG_THREADS) void dg_minpos_kernel(const u32 *__rest
             for (u32 m = 0; m < ds.sz[j]; m++) { const u32 q = pos[ds.gs[j] + m]; mn = q < mn ? q : mn; }
             sk = mn;
         } else sk = n + (u64)ds.h[j];
-        keys[e] = ((u64)ds.h[j] << 16) | (sk >> (kb - 16));        // kb >= 17 here (the list has at least 2^16 elements)
+        keys[e] = ((u64)ds.h[j] << DG_ORDER_BITS) | (kb > DG_ORDER_BITS ? sk >> (kb - DG_ORDER_BITS) : sk);
         vals[e] = ds.idx[j];
     }
 }
@@ -1470,7 +1496,7 @@ __global__ __launch_bounds__(256) void dg_unpack_kernel(const u64 *__restrict__ 
                                                         u32 *__restrict__ idx, u32 *__restrict__ head)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> 16); }
+    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> DG_ORDER_BITS); }
 }
 
 // Workgroup w looks at list elements [w * DG_OWN - DG_CAP, ... + DG_SPAN): LDS slot sl <-> element e = w * DG_OWN - DG_CAP + sl,
@@ -1782,10 +1808,12 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             dg_minpos_kernel<<<dim3((unsigned)((a + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a, n, kb, op.keys[0], op.vals[0]);
             HIPC(hipGetLastError());
         }
-        // the top 16 bits are what locality needs (groups whose smallest positions share a window of 2 n / 2^16 positions end
-        // up together, in their old relative order): two passes instead of four
+        // the top 24 bits are what locality needs: groups whose smallest positions share a window of 2 n / 2^24 positions (64 at
+        // n = 2^30, one wave's worth) end up together, in their old relative order -- three passes instead of four.  (16 bits
+        // were measurably too coarse: a 16 K-position window is worked on by workgroups on several XCDs at once, each of
+        // which fetches the window's rank lines into its own L2.)
         int ores = 0;
-        BWTS_TRY(radix_sort_pairs(ctx, op, a, 16, &ores));
+        BWTS_TRY(radix_sort_pairs(ctx, op, a, kb < DG_ORDER_BITS ? kb : DG_ORDER_BITS, &ores));
         {
             SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
             dg_unpack_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(op.keys[ores], op.vals[ores], a, kb, sets[0].idx, sets[0].head);

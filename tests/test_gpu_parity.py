@@ -14,6 +14,8 @@ import pytest
 import oracle_lib as O
 from test_oracle import ADVERSARIAL, KAT, REF, fib_word
 
+BIG = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_forward.json")))
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -309,8 +311,21 @@ def test_config3_zipf_1GiB_properties(ctx):
 
 
 def test_index_boundary_2p31(ctx):
-    """n just above 2^31: the inverse keeps its marks in a byte map, LF uses all 32 bits."""
-    _properties_at_scale(ctx, "zipf", (1 << 31) + 12345, 3)
+    """n just above 2^31, beyond the reference's int / saidx_t indices (mk_bwts_sa.c:26-27): the forward bytes are held against
+    the golden hash made by the oracle's 64-bit-index instance (tests/golden/big_forward.json, make_golden_big.py; that instance
+    is held against the pinned 32-bit one in test_oracle.py), then the size-independent properties."""
+    rec = [r for r in BIG["cases"] if r["kind"] == "zipf" and r["n"] == (1 << 31) + 12345][0]
+    n = rec["n"]
+    d_in, d_out = ctx.alloc(n), ctx.alloc(n)
+    try:
+        ctx.generate(rec["kind"], rec["seed"], n, d_in)
+        assert hashlib.sha256(d_in.download().tobytes()).hexdigest() == rec["sha256_in"]
+        ctx.forward_device(d_in, n, d_out)
+        assert hashlib.sha256(d_out.download().tobytes()).hexdigest() == rec["sha256_bwts"]
+    finally:
+        d_in.free()
+        d_out.free()
+    _properties_at_scale(ctx, rec["kind"], n, rec["seed"])
 
 
 def test_config4_dna_4GiB_properties(ctx, pkg):

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))));
 import numpy as np
 import oracle_lib as O
 import __graft_entry__ as ge
-pkg = ge.load_package(); ctx = pkg.Context(0)
+pkg = ge.load_package(); ctx = pkg.Context(0); ctx.set_timing(2)
 log2b = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 block = O.generate("zipf", 1 << log2b, 5)
 x = np.concatenate([block, block, block[: len(block) // 2], O.generate("zipf", 1000, 6), block])

@@ -23,7 +23,7 @@ def corpus(limit):
 
 limit = (1 << int(sys.argv[1])) if len(sys.argv) > 1 else 1 << 26
 x = np.frombuffer(corpus(limit), dtype=np.uint8)
-pkg = ge.load_package(); ctx = pkg.Context(0)
+pkg = ge.load_package(); ctx = pkg.Context(0); ctx.set_timing(2)
 for rep in range(2):
     y = ctx.forward(x)
 tm = ctx.timings().as_dict()

@@ -17,7 +17,7 @@ for v in range(4):
     c[rng.integers(0, len(c), size=k)] = rng.integers(32, 127, size=k, dtype=np.uint8)
     parts.append(c)
 x = np.concatenate(parts)
-pkg = ge.load_package(); ctx = pkg.Context(0)
+pkg = ge.load_package(); ctx = pkg.Context(0); ctx.set_timing(2)
 for rep in range(2):
     t0 = time.time(); y = ctx.forward(x); dt = time.time() - t0
 tm = ctx.timings().as_dict()

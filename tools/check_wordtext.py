@@ -19,7 +19,7 @@ def wordtext(nbytes, seed, vocab=50000):
         out += b" ".join(words[i] for i in idx) + b". "
     return np.frombuffer(bytes(out[:nbytes]), dtype=np.uint8)
 
-pkg = ge.load_package(); ctx = pkg.Context(0)
+pkg = ge.load_package(); ctx = pkg.Context(0); ctx.set_timing(2)
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 x = wordtext(1 << log2n, 3)
 for rep in range(2):
