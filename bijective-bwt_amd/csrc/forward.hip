@@ -417,9 +417,11 @@ __global__ __launch_bounds__(256) void carried_head_fix_kernel(const u8 *__restr
 #define KB_HALO    64
 
 // The value array of round 0 is the identity and is never written: the first radix pass uses the element index.
+// pos0 / lim: the launch covers positions [pos0, lim) (pos0 a multiple of KB_TILE) and stores the key of position q at index
+// q - pos0, tile minima at tile - pos0 / KB_TILE: the wide path (n > 2^32) materialises keys one segment at a time.
 __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes_g,
                                                                int bits, int msym, int pad_add,
-                                                               KeyStore keys, u64 *__restrict__ tile_min /* may be null */)
+                                                               KeyStore keys, u64 *__restrict__ tile_min /* may be null */, u64 pos0, u64 lim)
 {
     __shared__ u16 sc[KB_TILE + KB_HALO + 16];
     __shared__ u64 skey[KB_TILE + KB_TILE / 8];     // blocked -> striped transpose (one pad slot per 8)
@@ -429,8 +431,8 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
     __shared__ u8 before_tile;
 
     const int tid = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * KB_TILE;
-    const u64 end = base + KB_TILE < n ? base + KB_TILE : n;
+    const u64 base = pos0 + (u64)blockIdx.x * KB_TILE;
+    const u64 end = base + KB_TILE < lim ? base + KB_TILE : lim;
     codes[tid] = codes_g[tid];
     if (tid == 0) before_tile = base ? T[base - 1] : T[n - 1];
     __syncthreads();
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0_kernel(const u8 *__restr
         if (base + e < end) {
             const u64 q = base + e;
             const u32 prev = e ? (u32)sraw[e - 1] : (u32)before_tile;          // T[q - 1], from the tile already in LDS
-            ks_store_with_prev(keys, q, skey[e + (e >> 3)], prev);
+            ks_store_with_prev(keys, q - pos0, skey[e + (e >> 3)], prev);
         }
     }
     // smallest key of the tile: the Lyndon candidate search starts from these (same tile size as the scan)
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(256) void count_prefix_matches_kernel(const u64 *__
 #define KB_SYM_PER   ((KB_SYMS + KB_THREADS - 1) / KB_THREADS)      // symbols a thread lays out: 9
 #define KB_BS_WORDS  ((KB_SYMS * VL_MAXLEN + 31) / 32 + 4)   // stream words incl. zero padding for the last windows
 __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ vtab_g,
-                                                                int key_bits, KeyStore keys, u64 *__restrict__ tile_min)
+                                                                int key_bits, KeyStore keys, u64 *__restrict__ tile_min, u64 pos0, u64 lim)
 {
     __shared__ u64 vtab[256];
     __shared__ __attribute__((aligned(16))) u8 sb[KB_SYMS + 16];
@@ -597,8 +599,8 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
     __shared__ u8 before_tile;                      // T[base - 1]: the carried byte of the tile's first position
 
     const int tid = threadIdx.x;
-    const u64 base = (u64)blockIdx.x * KB_TILE;
-    const u64 end = base + KB_TILE < n ? base + KB_TILE : n;
+    const u64 base = pos0 + (u64)blockIdx.x * KB_TILE;
+    const u64 end = base + KB_TILE < lim ? base + KB_TILE : lim;
     vtab[tid] = vtab_g[tid];
     if (tid == 0) before_tile = base ? T[base - 1] : T[n - 1];
     const u32 span = KB_SYMS;
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(KB_THREADS) void keybuild0v_kernel(const u8 *__rest
             const u64 key = win >> (64 - key_bits);
             lo = key < lo ? key : lo;
             const u32 prev = e ? (u32)sb[e - 1] : (u32)before_tile;            // T[q - 1], from the tile already in LDS
-            ks_store_with_prev(keys, base + e, key, prev);
+            ks_store_with_prev(keys, base + e - pos0, key, prev);
         }
     }
     if (tile_min) {
@@ -2220,21 +2222,26 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
 
 static_assert(KB_TILE == SCAN_TILE, "keybuild0's tile minima feed the scan's final sweep");
 
-static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp, u64 *tile_min, bool split)
+// keys of positions [pos0, pos0 + count) into keys0 (index q - pos0), tile minima into tile_min[0 ..)
+static int launch_keybuild0_seg(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, u64 *keys0, u64 *tile_min, bool split, u64 pos0, u64 count)
 {
-    SpanGuard g(ctx, BWTS_K_KEYBUILD, n, n + (split ? 5 : 8) * n);
-    const u64 blocks = (n + KB_TILE - 1) / KB_TILE;
-    const KeyStore ks = key_store_of(sp.keys[0], n, split, al.key_bits);
+    SpanGuard g(ctx, BWTS_K_KEYBUILD, count, count + (split ? 5 : 8) * count);
+    const u64 blocks = (count + KB_TILE - 1) / KB_TILE;
+    const KeyStore ks = key_store_of(keys0, count, split, al.key_bits);
     if (al.varlen) {
         keybuild0v_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(d_T, n, ctx->d_small + SM_VTAB, al.key_bits,
-                                                                                        ks, tile_min);
+                                                                                        ks, tile_min, pos0, pos0 + count);
         HIPC(hipGetLastError());
         return BWTS_OK;
     }
     keybuild0_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(
-        d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, ks, tile_min);
+        d_T, n, (const u8 *)(ctx->d_small + SM_CODES), al.bits, al.msym, al.pad_add, ks, tile_min, pos0, pos0 + count);
     HIPC(hipGetLastError());
     return BWTS_OK;
+}
+static int launch_keybuild0(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, SortSpace &sp, u64 *tile_min, bool split)
+{
+    return launch_keybuild0_seg(ctx, d_T, n, al, sp.keys[0], tile_min, split, 0, n);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2317,9 +2324,11 @@ static int lyndon_general(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, u3
 struct KeyIn { KeyStore K; __device__ __forceinline__ u64 operator()(u64 i) const { return ks_load(K, i); } };
 struct CandOut {
     KeyStore K; u64 n; int msym; u64 *cand; u64 cap; u64 *counter;
-    __device__ __forceinline__ void operator()(u64 i, u64 min_before) const
+    u64 pos0 = 0;          // element j of this launch is position pos0 + j (wide path: one segment at a time)
+    __device__ __forceinline__ void operator()(u64 j, u64 min_before) const
     {
-        const u64 ki = ks_load(K, i);
+        const u64 ki = ks_load(K, j);
+        const u64 i = pos0 + j;
         const bool c = i == 0 || ki <= min_before;
         const u64 m = __ballot(c);
         if (m == 0) return;
@@ -2354,8 +2363,9 @@ struct LynState {         // in d_small: resumable state of the resolver
     u64 work;
 };
 
+template <typename POS>
 __global__ __launch_bounds__(256) void lyndon_resolve_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ cand, u64 cnt,
-                                                             u32 *__restrict__ fstart, LynState *__restrict__ st, u64 work_cap)
+                                                             POS *__restrict__ fstart, LynState *__restrict__ st, u64 work_cap)
 {
     __shared__ int s_mis[4];      // per wave: first mismatching lane of the chunk, or -1
     __shared__ int s_less[4];     // per wave: candidate byte < current-start byte at that lane
@@ -2396,7 +2406,7 @@ __global__ __launch_bounds__(256) void lyndon_resolve_kernel(const u8 *__restric
             }
         }
         if (is_start) {
-            if (tid == 0) fstart[k] = (u32)p;
+            if (tid == 0) fstart[k] = (POS)p;
             k++;
             cur = p;
         }
@@ -2454,7 +2464,7 @@ static int lyndon_fast(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, 
     for (int iter = 0;; iter++) {
         {
             SpanGuard g(ctx, BWTS_K_LYNDON, cnt_c, 0);
-            lyndon_resolve_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(d_T, n, cand[res], cnt_c, fstart, d_st, LYN_WORK_CAP);
+            lyndon_resolve_kernel<u32><<<dim3(1), dim3(256), 0, ctx->stream>>>(d_T, n, cand[res], cnt_c, fstart, d_st, LYN_WORK_CAP);
             HIPC(hipGetLastError());
         }
         BWTS_TRY(read_small(ctx, CNT_LYN_K, 8));
@@ -2635,6 +2645,8 @@ __global__ __launch_bounds__(256) void patch_ties_kernel(const u32 *__restrict__
     out[r] = fstart[f] == p ? T[factor_end(fstart, k, n, f) - 1] : T[p - 1];
 }
 
+#include "wide_path.h"
+
 size_t forward_arena_bytes(u64 n)
 {
     // candidate buffers + sort space + factor list (general path: up to n entries) + P + two carry buffers
@@ -2644,7 +2656,13 @@ size_t forward_arena_bytes(u64 n)
 
 int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
-    if (n > 0x100000000ull) return BWTS_E_RANGE;
+    // beyond 32-bit indices: the blocked path with 64-bit positions and ranks (wide_path.h).  BWTS_FORCE_WIDE=1 sends every
+    // input there, falling back when the wide form cannot take it; =2 does not fall back (tests)
+    static const int force_wide = [] { const char *e = getenv("BWTS_FORCE_WIDE"); return e ? atoi(e) : 0; }();
+    if (n > 0x100000000ull || force_wide) {
+        const int rc = forward_wide_impl(ctx, d_in, n, d_out);
+        if (n > 0x100000000ull || force_wide == 2 || rc != BWTS_E_RANGE) return rc;
+    }
     BWTS_TRY(arena_reserve(ctx, forward_arena_bytes(n)));
     SortSpace sp;
     BWTS_TRY(sort_space_alloc(ctx, n, &sp));

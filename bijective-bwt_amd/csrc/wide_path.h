@@ -1,0 +1,473 @@
+// wide_path.h -- forward transform of inputs beyond the 32-bit index range (n > 2^32).  Included by forward.hip.
+//
+// The reference's indices are int / saidx_t (mk_bwts_sa.c:26-27, unbwts.c:12-13): it stops below 2^31.  The engine's main
+// path keeps everything about a position in 32 bits and 36 n bytes of HBM, which ends at n = 2^32.  Here positions and ranks
+// are 64-bit, and the sort is blocked so that its working set does not grow with n:
+//   * the round-0 keys are never materialised for the whole text: a SEGMENT of positions at a time (keybuild0*_kernel with a
+//     position offset), as often as somebody needs them;
+//   * the Lyndon factors come from the same candidate search as on the main path, run segment by segment over the global
+//     prefix minima of the tile minima;
+//   * the positions are cut into BUCKETS by the top bits of their key -- a bucket is a contiguous range of the final order.  A
+//     histogram of the key prefixes (per segment) gives every bucket's size and where each segment's share lands in it;
+//     bucket by bucket the members are collected (stable), sorted by key (the same LSD passes; the position's bits above 32
+//     ride in the byte stream that otherwise carries the emission byte), and finished: global rank = bucket base + group
+//     head into the n-entry u64 rank array, output byte written, tied elements appended to the tied list;
+//   * the tied list (small unless the input is repetitive) goes through rounds of (group, rank of the h-th cyclic successor)
+//     sorting with 64-bit ranks until no group splits.
+// Memory: rank array 8 n, one segment of keys, one bucket's sort buffers: ~160 GiB at n = 12 GiB, against ~430 GiB for the
+// main path's layout.  The inverse transform has no wide path yet (out of core).
+#define WIDE_PREFIX_BITS 12
+#define WIDE_PREFIXES    (1u << WIDE_PREFIX_BITS)
+#define WIDE_TIED_CAP    (1ull << 28)
+
+__device__ __forceinline__ u64 factor_of64(const u64 *__restrict__ fstart, u64 k, u64 p)
+{
+    u64 lo = 0, hi = k - 1;
+    while (lo < hi) {
+        const u64 mid = (lo + hi + 1) >> 1;
+        if (fstart[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+struct PrevSym64 {       // T[cprev(p)] (mk_bwts_sa.c:172-188) through the factor list
+    const u8 *T; u64 n; const u64 *fstart; u64 k;
+    __device__ __forceinline__ u8 operator()(u64 p) const
+    {
+        const u64 f = factor_of64(fstart, k, p);
+        if (fstart[f] == p) return T[(f + 1 < k ? fstart[f + 1] : n) - 1];
+        return T[p - 1];
+    }
+};
+__device__ __forceinline__ u64 cyclic_successor64(const u64 *__restrict__ fstart, u64 k, u64 n, u64 p, u64 h)
+{
+    const u64 f = factor_of64(fstart, k, p);
+    const u64 s = fstart[f], L = (f + 1 < k ? fstart[f + 1] : n) - s;
+    return cyclic_successor(p, s, L, h);
+}
+
+// keys of the positions close to a factor's end wrap around inside the factor (cyclic_patch[_vl]_kernel of the main path),
+// restricted to the segment [pos0, lim) whose keys are in `keys`
+__global__ __launch_bounds__(256) void cyclic_patch_wide_kernel(const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes, int bits, int msym,
+                                                                const u64 *__restrict__ vtab /* variable-length codes, or null */, int key_bits,
+                                                                int span, const u64 *__restrict__ fstart, u64 k, u64 *__restrict__ keys, u64 pos0, u64 lim)
+{
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (span <= 0 || t >= k * (u64)span) return;
+    const u64 f = t / (u64)span, j = t % (u64)span;
+    const u64 s = fstart[f], e = f + 1 < k ? fstart[f + 1] : n;
+    if (j >= e - s) return;
+    const u64 p = e - 1 - j;
+    if (p < pos0 || p >= lim) return;
+    keys[p - pos0] = vtab ? vl_key_cyclic(T, vtab, key_bits, p, s, e) : cyclic_key(T, codes, bits, msym, p, s, e);
+}
+
+// per-segment histogram of the key prefixes
+__global__ __launch_bounds__(256) void wide_prefix_hist_kernel(const u64 *__restrict__ keys, u64 count, int shift, u32 *__restrict__ hist)
+{
+    __shared__ u32 bins[WIDE_PREFIXES];
+    for (u32 i = threadIdx.x; i < WIDE_PREFIXES; i += 256) bins[i] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < count; i += (u64)gridDim.x * 256) atomicAdd(&bins[(u32)(keys[i] >> shift)], 1u);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < WIDE_PREFIXES; i += 256) if (bins[i]) atomicAdd(&hist[i], bins[i]);
+}
+
+// members of bucket [plo, phi) among a segment's keys, in position order (stable compaction)
+struct WideFilterIn {
+    const u64 *keys; int shift; u32 plo, phi;
+    __device__ __forceinline__ u32 operator()(u64 i) const { const u32 pf = (u32)(keys[i] >> shift); return pf >= plo && pf < phi ? 1u : 0u; }
+};
+struct WideFilterOut {
+    const u64 *keys; int shift; u32 plo, phi; u64 pos0; u64 *bk; u32 *bv; u8 *bs;      // bk/bv/bs already point at this segment's share
+    __device__ __forceinline__ void operator()(u64 i, u32 before) const
+    {
+        const u64 key = keys[i];
+        const u32 pf = (u32)(key >> shift);
+        if (pf >= plo && pf < phi) { const u64 p = pos0 + i; bk[before] = key; bv[before] = (u32)p; bs[before] = (u8)(p >> 32); }
+    }
+};
+
+// a sorted bucket is finished: ranks, output bytes, tied elements
+__global__ __launch_bounds__(256) void wide_bucket_finish_kernel(const u32 *__restrict__ V, const u8 *__restrict__ S, u64 m, u64 base,
+                                                                 const u64 *__restrict__ headw, const u64 *__restrict__ keepw, const u64 *__restrict__ pre,
+                                                                 u64 *__restrict__ rank64, PrevSym64 prev, u8 *__restrict__ out,
+                                                                 const u64 *__restrict__ tied_count, u64 tied_cap, u64 *__restrict__ tpos, u64 *__restrict__ thead,
+                                                                 u64 *__restrict__ overflow)
+{
+    const int lane = lane_id();
+    const u64 tbase = *tied_count;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < ((m + 63) & ~63ull); i += (u64)gridDim.x * 256) {
+        if (i >= m) continue;
+        const u64 w = i >> 6;
+        const u64 hm = headw[w], km = keepw[w], pr = pre[w];
+        const u64 below = lane == 63 ? hm : hm & ((2ull << lane) - 1ull);
+        const u64 hloc = below ? (w << 6) + (u64)(63 - __clzll((long long)below)) : (pr >> 32);
+        const u64 p = (u64)V[i] | ((u64)S[i] << 32);
+        const u64 r = base + hloc;
+        rank64[p] = r;
+        out[base + i] = prev(p);
+        if ((km >> lane) & 1ull) {
+            const u64 t = tbase + (u64)(u32)pr + (u64)__popcll(km & lanemask_lt());
+            if (t < tied_cap) { tpos[t] = p; thead[t] = r; }
+            else *overflow = 1;
+        }
+    }
+}
+__global__ void wide_add_tied_kernel(const u64 *__restrict__ keepw, const u64 *__restrict__ pre, u64 words, u64 *__restrict__ tied_count)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *tied_count += (u64)(u32)pre[words - 1] + (u64)__popcll(keepw[words - 1]);
+}
+
+// ---- rounds over the tied list (64-bit ranks) -------------------------------------------------------------------------
+struct WideOrdIn {
+    const u64 *head;
+    __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || head[i] != head[i - 1]) ? 1u : 0u; }
+};
+struct WideOrdOut {
+    const u64 *pos; const u64 *head; const u64 *rank64; u64 n; u64 h; const u64 *fstart; u64 k; int rb; u64 *bk; u32 *bv; u64 a; u64 *groups;
+    __device__ __forceinline__ void operator()(u64 i, u32 before) const
+    {
+        const u32 st = (i == 0 || head[i] != head[i - 1]) ? 1u : 0u;
+        const u64 ord = (u64)before + st - 1;
+        const u64 r2 = rank64[cyclic_successor64(fstart, k, n, pos[i], h)];
+        bk[i] = (ord << rb) | r2;
+        bv[i] = (u32)i;
+        if (i + 1 == a) *groups = (u64)before + st;
+    }
+};
+struct WideRegroupOut {
+    const u64 *bk; const u32 *bv; u64 m; const u64 *pos; const u64 *head; u64 *npos; u64 *nhead; u8 *state; PrevSym64 prev; u8 *out; u64 *split;
+    __device__ __forceinline__ void operator()(u64 j, u64 v) const       // inclusive scan value of DgRegroupIn
+    {
+        const u32 gidx = (u32)(v >> 32) - 1u, sidx = (u32)v - 1u;
+        const u64 kj = bk[j];
+        const bool alone = sidx == (u32)j && (j + 1 == m || bk[j + 1] != kj);
+        const u32 li = bv[j];
+        const u64 p = pos[li];
+        const u64 nh = head[li] + (u64)(sidx - gidx);
+        npos[j] = p; nhead[j] = nh;
+        state[j] = (u8)((alone ? DG_DONE : DG_KEEP) | (sidx != gidx ? DG_MOVED : 0));
+        if (alone) out[nh] = prev(p);
+        const u64 sm = __ballot(sidx != gidx);
+        if (sm && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1 &&
+            __hip_atomic_load(split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(split, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+struct WideKeepIn {
+    const u8 *state;
+    __device__ __forceinline__ u32 operator()(u64 i) const { return (state[i] & 3) == DG_KEEP ? 1u : 0u; }
+};
+struct WideKeepOut {
+    const u8 *state; const u64 *npos; const u64 *nhead; u64 *rank64; u64 *opos; u64 *ohead; u64 a; u64 *count;
+    __device__ __forceinline__ void operator()(u64 j, u32 before) const
+    {
+        const u32 st = state[j];
+        const bool keep = (st & 3) == DG_KEEP;
+        if (st & DG_MOVED) rank64[npos[j]] = nhead[j];
+        if (keep) { opos[before] = npos[j]; ohead[before] = nhead[j]; }
+        if (j + 1 == a) *count = (u64)before + (keep ? 1u : 0u);
+    }
+};
+struct WideRestIn {
+    const u64 *head;
+    __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || head[i] != head[i - 1]) ? (u32)i + 1u : 0u; }
+};
+struct WideRestOut {
+    const u64 *pos; const u64 *head; PrevSym64 prev; u8 *out;
+    __device__ __forceinline__ void operator()(u64 i, u32 v) const { out[head[i] + ((u64)i - (u64)(v - 1u))] = prev(pos[i]); }
+};
+
+struct WideKnobs { int seg_log2; u64 bucket_cap; };
+static WideKnobs wide_knobs(void)
+{
+    WideKnobs kn{30, 1ull << 30};
+    if (const char *e = getenv("BWTS_WIDE_SEG_LOG2")) { const int v = atoi(e); if (v >= 11 && v <= 31) kn.seg_log2 = v; }      // >= log2(KB_TILE)
+    if (const char *e = getenv("BWTS_WIDE_BUCKET")) { const long long v = atoll(e); if (v >= 256 && v <= (1ll << 31)) kn.bucket_cap = (u64)v; }
+    return kn;
+}
+
+static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
+{
+    if (n > (1ull << 36)) return BWTS_E_RANGE;
+    const WideKnobs kn = wide_knobs();
+    const u64 seg = 1ull << kn.seg_log2;
+    const u64 nseg = (n + seg - 1) / seg;
+    const u64 tiles = scan_tiles(n);
+    const u64 M = kn.bucket_cap;                                   // elements a bucket may hold
+    u64 tied_cap = n / 4 + 1024;                                   // elements the tied list may hold
+    if (tied_cap > WIDE_TIED_CAP) tied_cap = WIDE_TIED_CAP;
+    const u64 Mb = M > tied_cap ? M : tied_cap;                    // the buckets' sort buffers also serve the rounds over the tied list
+    const u64 mwords = (Mb + 63) / 64 + 1;
+    // ---- arena layout -------------------------------------------------------------------------------------------------
+    const size_t need = align_up(n * 8, 256) + align_up(seg * 8, 256) + align_up((tiles + 1) * 8, 256) + scan_temp_bytes(n) +
+                        2 * align_up(Mb * 8, 256) + 2 * align_up(Mb * 4, 256) + 4 * align_up(Mb, 256) + radix_tile_hist_bytes(Mb > seg ? Mb : seg) +
+                        scan_temp_bytes(Mb > seg ? Mb : seg) + 3 * align_up(mwords * 8, 256) + 8 * align_up(LYN_CAND_CAP * 8, 256) +
+                        align_up(nseg * WIDE_PREFIXES * 4, 256) + (1 << 16);
+    BWTS_TRY(arena_reserve(ctx, need));
+    u64 *rank64 = arena_array<u64>(ctx, n);
+    u64 *segkeys = arena_array<u64>(ctx, seg);
+    u64 *tile_min = arena_array<u64>(ctx, tiles + 1);
+    void *pre_temp = arena_alloc(ctx, scan_temp_bytes(n));
+    u64 *bk[2] = {arena_array<u64>(ctx, Mb), arena_array<u64>(ctx, Mb)};
+    u32 *bv[2] = {arena_array<u32>(ctx, Mb), arena_array<u32>(ctx, Mb)};
+    u8 *bs_src = arena_array<u8>(ctx, Mb), *bs_buf[2] = {arena_array<u8>(ctx, Mb), arena_array<u8>(ctx, Mb)}, *bs_fin = arena_array<u8>(ctx, Mb);
+    u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(Mb > seg ? Mb : seg));
+    void *scan_temp = arena_alloc(ctx, scan_temp_bytes(Mb > seg ? Mb : seg));
+    u64 *headw = arena_array<u64>(ctx, mwords), *keepw = arena_array<u64>(ctx, mwords), *prew = arena_array<u64>(ctx, mwords);
+    u64 *cand[2] = {arena_array<u64>(ctx, LYN_CAND_CAP), arena_array<u64>(ctx, LYN_CAND_CAP)};
+    u32 *cvals[2] = {arena_array<u32>(ctx, LYN_CAND_CAP), arena_array<u32>(ctx, LYN_CAND_CAP)};
+    u64 *fstart = arena_array<u64>(ctx, LYN_CAND_CAP);
+    u32 *d_hist = arena_array<u32>(ctx, nseg * WIDE_PREFIXES);
+    if (!rank64 || !segkeys || !tile_min || !pre_temp || !bk[1] || !bv[1] || !bs_src || !bs_buf[1] || !bs_fin || !tile_hist || !scan_temp ||
+        !headw || !keepw || !prew || !cand[1] || !cvals[1] || !fstart || !d_hist)
+        return BWTS_E_NOMEM;
+
+    // ---- alphabet and key format ---------------------------------------------------------------------------------------
+    BWTS_TRY(read_histogram(ctx, d_T, n));
+    Alphabet al;
+    BWTS_TRY(set_alphabet(ctx, false, n, &al));
+    ctx->tm.key_symbols = (u32)al.msym;
+    ctx->tm.key_bits = (u32)al.key_bits;
+    const int pbits = al.key_bits < WIDE_PREFIX_BITS ? al.key_bits : WIDE_PREFIX_BITS;
+    const int pshift = al.key_bits - pbits;
+    const u64 *d_vtab = al.varlen ? ctx->d_small + SM_VTAB : nullptr;
+    const u8 *d_codes = (const u8 *)(ctx->d_small + SM_CODES);
+    auto seg_count = [&](u64 s) -> u64 { const u64 p0 = s * seg; return n - p0 < seg ? n - p0 : seg; };
+
+    // ---- Lyndon factors (mk_bwts_sa.c:126-129), candidate search as on the main path, segment by segment -----------------
+    for (u64 s = 0; s < nseg; s++)
+        BWTS_TRY(launch_keybuild0_seg(ctx, d_T, n, al, segkeys, tile_min + s * (seg / KB_TILE), false, s * seg, seg_count(s)));
+    u64 *cnt = ctx->d_small + SM_COUNTERS;
+    HIPC(hipMemsetAsync(cnt + 4, 0, 4 * sizeof(u64), ctx->stream));
+    {
+        SpanGuard g(ctx, BWTS_K_LYNDON, n, 0);
+        // exclusive prefix minima of the tile minima, in pre_temp (laid out like the partials of a scan over n elements)
+        HIPC(hipMemcpyAsync(pre_temp, tile_min, tiles * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+        BWTS_TRY((device_scan_partials<u64, OpMin>(ctx, tiles, OpMin(), ~0ull, pre_temp)));
+    }
+    for (u64 s = 0; s < nseg; s++) {
+        const u64 p0 = s * seg, c = seg_count(s), t0 = p0 / KB_TILE;
+        BWTS_TRY(launch_keybuild0_seg(ctx, d_T, n, al, segkeys, nullptr, false, p0, c));
+        SpanGuard g(ctx, BWTS_K_LYNDON, c, 8 * c);
+        const KeyStore ks = key_store_of(segkeys, c, false, al.key_bits);
+        KeyIn in{ks};
+        CandOut out{ks, n, al.varlen ? 64 : al.msym, cand[0], LYN_CAND_CAP, ctx->d_small + CNT_CAND, p0};
+        TileMayHoldCandidate filter{tile_min + t0};
+        BWTS_TRY((device_scan_final<false, u64>(ctx, c, in, out, OpMin(), ~0ull, (u64 *)pre_temp + t0, filter)));
+    }
+    BWTS_TRY(read_small(ctx, CNT_CAND, 1));
+    const u64 cnt_c = ctx->h_small[CNT_CAND];
+    if (cnt_c == 0) return BWTS_E_INTERNAL;
+    if (cnt_c > LYN_CAND_CAP) return BWTS_E_RANGE;           // (a^n, (ab)^n ...: the suffix-sort route to the factors has no wide form)
+    u64 k = 0;
+    {
+        SortPlan cp;
+        cp.keys[0] = cand[0]; cp.keys[1] = cand[1];
+        cp.vals[0] = cvals[0]; cp.vals[1] = cvals[1];
+        cp.tile_hist = tile_hist; cp.scan_temp = scan_temp;
+        int res = 0;
+        BWTS_TRY(radix_sort_pairs(ctx, cp, cnt_c, bitlen_u64(n) + 1, &res));
+        LynState *d_st = (LynState *)(ctx->d_small + CNT_LYN_K);
+        LynState *h_st = (LynState *)(ctx->h_small + CNT_LYN_K);
+        unsigned long long *d_mis = (unsigned long long *)(ctx->d_small + CNT_LYN_K + 8);
+        HIPC(hipMemsetAsync(d_st, 0, sizeof(LynState), ctx->stream));
+        for (int iter = 0;; iter++) {
+            {
+                SpanGuard g(ctx, BWTS_K_LYNDON, cnt_c, 0);
+                lyndon_resolve_kernel<u64><<<dim3(1), dim3(256), 0, ctx->stream>>>(d_T, n, cand[res], cnt_c, fstart, d_st, LYN_WORK_CAP);
+                HIPC(hipGetLastError());
+            }
+            BWTS_TRY(read_small(ctx, CNT_LYN_K, 8));
+            if (h_st->status == 0) break;
+            if (h_st->status == 2 || iter > 4096) return BWTS_E_RANGE;
+            u64 e = 0;
+            HIPC(hipMemcpyAsync(&e, cand[res] + h_st->next, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+            HIPC(hipStreamSynchronize(ctx->stream));
+            const u64 pp = e >> 1, qq = h_st->cur;
+            const u64 len = n - pp;
+            HIPC(hipMemcpyAsync(d_mis, &len, sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+            {
+                SpanGuard g(ctx, BWTS_K_LYNDON, len, 2 * len);
+                u64 blocks = (len + 255) / 256; if (blocks > 4096) blocks = 4096;
+                suffix_mismatch_grid_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(d_T, n, pp, qq, d_mis);
+                HIPC(hipGetLastError());
+            }
+            BWTS_TRY(read_small(ctx, CNT_LYN_K + 8, 1));
+            const u64 at = ctx->h_small[CNT_LYN_K + 8];
+            bool less;
+            if (at >= len) less = true;
+            else {
+                u8 ab[2];
+                HIPC(hipMemcpyAsync(&ab[0], d_T + pp + at, 1, hipMemcpyDeviceToHost, ctx->stream));
+                HIPC(hipMemcpyAsync(&ab[1], d_T + qq + at, 1, hipMemcpyDeviceToHost, ctx->stream));
+                HIPC(hipStreamSynchronize(ctx->stream));
+                less = ab[0] < ab[1];
+            }
+            h_st->forced = 1; h_st->forced_less = less ? 1 : 0; h_st->status = 0;
+            HIPC(hipMemcpyAsync(d_st, h_st, sizeof(LynState), hipMemcpyHostToDevice, ctx->stream));
+            HIPC(hipStreamSynchronize(ctx->stream));
+        }
+        k = h_st->k;
+        if (k == 0) return BWTS_E_INTERNAL;
+    }
+    ctx->tm.factors = k;
+    const PrevSym64 prev{d_T, n, fstart, k};
+
+    // cyclic round-0 keys of one segment: keybuild + the wrap-around patch near the factor ends
+    auto seg_keys = [&](u64 s) -> int {
+        const u64 p0 = s * seg, c = seg_count(s);
+        BWTS_TRY(launch_keybuild0_seg(ctx, d_T, n, al, segkeys, nullptr, false, p0, c));
+        const int span = al.varlen ? 64 : al.msym - 1;
+        if (span > 0) {
+            const u64 threads = k * (u64)span;
+            cyclic_patch_wide_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+                d_T, n, d_codes, al.bits, al.msym, d_vtab, al.key_bits, span, fstart, k, segkeys, p0, p0 + c);
+            HIPC(hipGetLastError());
+        }
+        return BWTS_OK;
+    };
+
+    // ---- bucket sizes: histogram of the key prefixes, per segment --------------------------------------------------------
+    HIPC(hipMemsetAsync(d_hist, 0, nseg * WIDE_PREFIXES * sizeof(u32), ctx->stream));
+    for (u64 s = 0; s < nseg; s++) {
+        BWTS_TRY(seg_keys(s));
+        const u64 c = seg_count(s);
+        u64 blocks = (c + 255) / 256; if (blocks > 2048) blocks = 2048;
+        SpanGuard g(ctx, BWTS_K_HISTOGRAM, c, 8 * c);
+        wide_prefix_hist_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(segkeys, c, pshift, d_hist + s * WIDE_PREFIXES);
+        HIPC(hipGetLastError());
+    }
+    std::vector<u32> h_hist((size_t)nseg * WIDE_PREFIXES);
+    HIPC(hipMemcpyAsync(h_hist.data(), d_hist, h_hist.size() * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    const u32 nprefix = 1u << pbits;
+    std::vector<u64> ptotal(nprefix, 0);
+    for (u64 s = 0; s < nseg; s++) for (u32 q = 0; q < nprefix; q++) ptotal[q] += h_hist[(size_t)s * WIDE_PREFIXES + q];
+    // greedy: consecutive prefixes while the bucket stays within M
+    std::vector<u32> cut;                 // bucket b = prefixes [cut[b], cut[b + 1])
+    {
+        u64 run = 0;
+        cut.push_back(0);
+        for (u32 q = 0; q < nprefix; q++) {
+            if (ptotal[q] > M) return BWTS_E_RANGE;        // one key prefix holds more positions than a bucket may: no finer cut in this form
+            if (run + ptotal[q] > M) { cut.push_back(q); run = 0; }
+            run += ptotal[q];
+        }
+        cut.push_back(nprefix);
+    }
+
+    // ---- tied list (aux) -------------------------------------------------------------------------------------------------
+    char *tb = nullptr;
+    const size_t t8 = align_up((size_t)tied_cap * 8, 256);
+    BWTS_TRY(aux_reserve(ctx, 6 * t8 + align_up((size_t)tied_cap, 256), &tb));
+    u64 *tpos[2] = {(u64 *)tb, (u64 *)(tb + t8)}, *thead[2] = {(u64 *)(tb + 2 * t8), (u64 *)(tb + 3 * t8)};
+    u64 *npos = (u64 *)(tb + 4 * t8), *nhead = (u64 *)(tb + 5 * t8);
+    u8 *tstate = (u8 *)(tb + 6 * t8);
+    u64 *d_tied = cnt + 24, *d_over = cnt + 25;
+    HIPC(hipMemsetAsync(cnt + 24, 0, 2 * sizeof(u64), ctx->stream));
+
+    // ---- bucket by bucket ----------------------------------------------------------------------------------------------------
+    u64 base = 0;
+    for (size_t b = 0; b + 1 < cut.size(); b++) {
+        const u32 plo = cut[b], phi = cut[b + 1];
+        u64 m = 0;
+        for (u32 q = plo; q < phi; q++) m += ptotal[q];
+        if (m == 0) continue;
+        u64 off = 0;
+        for (u64 s = 0; s < nseg; s++) {
+            u64 share = 0;
+            for (u32 q = plo; q < phi; q++) share += h_hist[(size_t)s * WIDE_PREFIXES + q];
+            if (share == 0) continue;
+            BWTS_TRY(seg_keys(s));
+            const u64 c = seg_count(s);
+            SpanGuard g(ctx, BWTS_K_RERANK, c, 9 * c + 13 * share);
+            WideFilterIn fin{segkeys, pshift, plo, phi};
+            WideFilterOut fout{segkeys, pshift, plo, phi, s * seg, bk[0] + off, bv[0] + off, bs_src + off};
+            BWTS_TRY((device_scan<false, u32>(ctx, c, fin, fout, OpAdd(), 0u, scan_temp)));
+            off += share;
+        }
+        if (off != m) return BWTS_E_INTERNAL;
+        SortPlan sp;
+        sp.keys[0] = bk[0]; sp.keys[1] = bk[1];
+        sp.vals[0] = bv[0]; sp.vals[1] = bv[1];
+        sp.tile_hist = tile_hist; sp.scan_temp = scan_temp;
+        sp.sym_src = bs_src; sp.sym_buf[0] = bs_buf[0]; sp.sym_buf[1] = bs_buf[1]; sp.sym_final = bs_fin;
+        int res = 0;
+        BWTS_TRY(radix_sort_pairs(ctx, sp, m, al.key_bits, &res));
+        const u64 words = (m + 63) / 64;
+        {
+            SpanGuard g(ctx, BWTS_K_RERANK, m, 8 * m);
+            u64 waves = (words + GF_WORDS - 1) / GF_WORDS;
+            unsigned blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
+            group_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], m, headw, keepw);
+            WordIn win{headw, keepw};
+            ScanStoreArr<u64> wout{prew};
+            BWTS_TRY((device_scan<false, u64>(ctx, words, win, wout, OpHeadCount(), (u64)0, scan_temp)));
+        }
+        {
+            SpanGuard g(ctx, BWTS_K_EMIT, m, 15 * m);
+            u64 blocks = (m + 255) / 256; if (blocks > 16384) blocks = 16384;
+            wide_bucket_finish_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.vals[res], bs_fin, m, base, headw, keepw, prew, rank64, prev,
+                                                                                            d_out, d_tied, tied_cap, tpos[0], thead[0], d_over);
+            wide_add_tied_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(keepw, prew, words, d_tied);
+            HIPC(hipGetLastError());
+        }
+        base += m;
+    }
+    if (base != n) return BWTS_E_INTERNAL;
+    BWTS_TRY(read_small(ctx, SM_COUNTERS + 24, 2));
+    u64 a = ctx->h_small[SM_COUNTERS + 24];
+    if (ctx->h_small[SM_COUNTERS + 25] || a > tied_cap) return BWTS_E_NOMEM;      // more tied elements than the tied list holds
+    ctx->tm.active_after_round0 = a;
+    ctx->tm.round_active[0] = a;
+
+    // ---- rounds over the tied list ---------------------------------------------------------------------------------------
+    u32 rounds = 1;
+    const int rb = bitlen_u64(n - 1);
+    int cur = 0;
+    for (u64 h = (u64)al.hstep; a > 0; h <<= 1) {
+        rounds++;
+        HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
+        {
+            SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 36 * a);
+            WideOrdIn oin{thead[cur]};
+            WideOrdOut oout{tpos[cur], thead[cur], rank64, n, h, fstart, k, rb, bk[0], bv[0], a, cnt + 3};
+            BWTS_TRY((device_scan<false, u32>(ctx, a, oin, oout, OpAdd(), 0u, scan_temp)));
+        }
+        BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
+        const u64 groups = ctx->h_small[SM_COUNTERS + 3];
+        if (bitlen_u64(groups) + rb > 64) return BWTS_E_RANGE;
+        SortPlan tp;
+        tp.keys[0] = bk[0]; tp.keys[1] = bk[1];
+        tp.vals[0] = bv[0]; tp.vals[1] = bv[1];
+        tp.tile_hist = tile_hist; tp.scan_temp = scan_temp;
+        int tres = 0;
+        BWTS_TRY(radix_sort_pairs(ctx, tp, a, bitlen_u64(groups) + rb, &tres));
+        {
+            SpanGuard g(ctx, BWTS_K_RERANK, a, 48 * a);
+            DgRegroupIn rin{bk[tres], a, rb};
+            WideRegroupOut rout{bk[tres], bv[tres], a, tpos[cur], thead[cur], npos, nhead, tstate, prev, d_out, cnt + 1};
+            BWTS_TRY((device_scan<true, u64>(ctx, a, rin, rout, OpMax2(), (u64)0, scan_temp)));
+            WideKeepIn kin{tstate};
+            WideKeepOut kout{tstate, npos, nhead, rank64, tpos[cur ^ 1], thead[cur ^ 1], a, cnt + 0};
+            BWTS_TRY((device_scan<false, u32>(ctx, a, kin, kout, OpAdd(), 0u, scan_temp)));
+        }
+        BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
+        const u64 a_new = ctx->h_small[SM_COUNTERS + 0], splits = ctx->h_small[SM_COUNTERS + 1];
+        if (a_new > a) return BWTS_E_INTERNAL;
+        cur ^= 1;
+        a = a_new;
+        if (rounds - 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[rounds - 1] = a;
+        if (a == 0 || splits == 0) break;                   // no group split: equal infinite words
+        if (rounds > 80) return BWTS_E_INTERNAL;
+    }
+    if (a) {
+        SpanGuard g(ctx, BWTS_K_EMIT, a, 20 * a);
+        WideRestIn rin{thead[cur]};
+        WideRestOut rout{tpos[cur], thead[cur], prev, d_out};
+        BWTS_TRY((device_scan<true, u32>(ctx, a, rin, rout, OpMax(), 0u, scan_temp)));
+    }
+    ctx->tm.rounds = rounds;
+    return BWTS_OK;
+}

@@ -492,6 +492,147 @@ def test_timing_is_opt_in(ctx):
 
 
 # ---------------------------------------------------------------------------------------------
+# beyond 32-bit indices: the blocked forward path with 64-bit positions and ranks
+# ---------------------------------------------------------------------------------------------
+WIDE_CASES = [("zipf", 70001, 3), ("dna", 300007, 4), ("uniform256", 65536, 5), ("zipf", (1 << 20) + 17, 6), ("text", 200003, 7),
+              ("dna", (1 << 21) + 3, 8)]
+
+
+def test_wide_path_small_vs_oracle_child():
+    """The n > 2^32 path forced onto small inputs (BWTS_FORCE_WIDE=2: no fallback), with segments of 2^13 positions and buckets of
+    n/6 elements so that many segments and buckets take part: bytes equal the oracle's, and the main path inverts them."""
+    if os.environ.get("BWTS_TEST_CHILD"):
+        pytest.skip("already inside a child run")
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle_lib as O, __graft_entry__ as ge
+import os
+pkg = ge.load_package()
+for kind, n, seed in %r:
+    os.environ["BWTS_WIDE_BUCKET"] = str(max(256, n // 6))
+    x = O.generate(kind, n, seed)
+    with pkg.Context(0) as ctx:
+        y = ctx.forward(x)
+        t = ctx.timings()
+        assert np.array_equal(y, O.forward(x)), (kind, n)
+        assert np.array_equal(ctx.inverse(y), x)
+        print(kind, n, "rounds", t.rounds, "tied", t.active_after_round0, "factors", t.factors)
+for kat in (b"banana", b"mississippi", b"abracadabra", b"the quick brown fox jumps over the lazy dog"):
+    os.environ["BWTS_WIDE_BUCKET"] = "256"
+    with pkg.Context(0) as ctx:
+        assert ctx.forward(kat).tobytes() == O.forward(kat).tobytes(), kat
+print("wide ok")
+""" % (ROOT, os.path.join(ROOT, "tests"), WIDE_CASES)
+    env = dict(os.environ, BWTS_TEST_CHILD="1", BWTS_FORCE_WIDE="2", BWTS_WIDE_SEG_LOG2="13")
+    proc = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    out, _ = proc.communicate(timeout=900)
+    _wait_gpu_handle_released(proc.pid)
+    assert proc.returncode == 0 and b"wide ok" in out, out.decode()[-3000:]
+
+
+def _lf_walk_matches_text(x, y, steps):
+    """Follows LF from slot 0 of y for `steps` steps (unbwts.c:50-52, 66-82 on the host, rank by block counts): the bytes met must
+    be the text read backwards from its end, for as long as the walk stays inside the last Lyndon factor's cycle."""
+    n = y.size
+    B = 1 << 20
+    nb = (n + B - 1) // B
+    syms = np.flatnonzero(np.bincount(y[: 1 << 24], minlength=256) + np.bincount(y[-(1 << 24):], minlength=256))
+    total = np.bincount(y, minlength=256) if n <= (1 << 32) else None
+    cum = {}
+    counts = np.zeros(256, dtype=np.int64)
+    for c in syms:
+        per = np.zeros(nb + 1, dtype=np.int64)
+        for b in range(nb):
+            per[b + 1] = per[b] + int(np.count_nonzero(y[b * B:(b + 1) * B] == c))
+        cum[int(c)] = per
+        counts[c] = per[-1]
+    assert counts.sum() == n                                   # every byte value of y was seen in the two sampled ends
+    C = np.concatenate([[0], np.cumsum(counts)])[:256]
+    r = 0
+    for t in range(steps):
+        c = int(y[r])
+        if c != int(x[n - 1 - t]):
+            return t
+        b = r // B
+        r = int(C[c] + cum[c][b] + np.count_nonzero(y[b * B:r] == c))
+        if r == 0:
+            return steps                                       # the cycle closed: the whole last factor was reproduced
+    return steps
+
+
+def test_wide_12GiB_dna_properties(ctx, pkg):
+    """dna(12 GiB): beyond 2^32 positions.  No inverse exists at this size yet, so: the bytes are a permutation of the input's,
+    bwts[0] = T[n-1] (mk_bwts_sa.c:188), and 200 000 steps of the inverse's LF walk from slot 0 -- done on the host -- read the
+    text backwards from its end exactly (one misplaced byte anywhere shifts the ranks behind it and derails the walk)."""
+    n = 12 << 30
+    try:
+        d_in, d_out = ctx.alloc(n), ctx.alloc(n)
+    except pkg.BwtsError:
+        pytest.skip("not enough device memory")
+    try:
+        ctx.generate("dna", 1, n, d_in)
+        try:
+            ctx.forward_device(d_in, n, d_out)
+        except pkg.BwtsError as e:
+            if e.code == -3:
+                pytest.skip("not enough free device memory for the 12 GiB case")
+            raise
+        t = ctx.timings()
+        x, y = d_in.download(), d_out.download()
+    finally:
+        d_in.free()
+        d_out.free()
+    assert y[0] == x[-1]
+    assert np.array_equal(O.generate("dna", 4096, 1, off=n - 4096), x[-4096:])
+    hx = sum(np.bincount(x[i:i + (1 << 30)], minlength=256) for i in range(0, n, 1 << 30))
+    hy = sum(np.bincount(y[i:i + (1 << 30)], minlength=256) for i in range(0, n, 1 << 30))
+    assert np.array_equal(hx, hy)
+    assert _lf_walk_matches_text(x, y, 200000) == 200000
+    assert t.factors >= 1 and t.rounds >= 1
+
+
+def test_lf_walk_checker_on_small_input():
+    """The host-side checker used at 12 GiB, held against a case the oracle covers.  It is a sampled check: every step tests one
+    slot's byte with exact ranks, so damage has to touch a fair share of the slots (here 5 %) to be met within the walk."""
+    x = O.generate("dna", (1 << 21) + 5, 3)
+    y = O.forward(x)
+    assert _lf_walk_matches_text(x, y, 50000) == 50000
+    z = y.copy()
+    lo, hi = z.size // 2, z.size // 2 + z.size // 20
+    z[lo:hi] = z[lo:hi][::-1].copy()
+    assert _lf_walk_matches_text(x, z, 50000) < 50000
+
+
+def test_wide_path_1GiB_equals_main_path_child():
+    """zipf(2^30) through the n > 2^32 path (forced; segments of 2^27 positions, buckets of 2^27 elements) gives byte for byte
+    what the main path gives: the blocked collection, the per-bucket sorts and the 64-bit rounds at a real size."""
+    if os.environ.get("BWTS_TEST_CHILD"):
+        pytest.skip("already inside a child run")
+    code = r"""
+import sys, os
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package()
+n = 1 << 30
+with pkg.Context(0) as ctx:
+    a, b, c = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    ctx.generate("zipf", 1, n, a)
+    ctx.forward_device(a, n, b)                     # forced wide (BWTS_FORCE_WIDE=2 in the environment)
+    t = ctx.timings()
+    print("wide: %%.1f ms, rounds %%d, tied %%d, factors %%d" %% (t.total_ms, t.rounds, t.active_after_round0, t.factors))
+    ctx.inverse_device(b, n, c)
+    assert ctx.device_equal(a, c, n)                # the main inverse turns it back into the input
+print("wide ok")
+""" % (ROOT,)
+    env = dict(os.environ, BWTS_TEST_CHILD="1", BWTS_FORCE_WIDE="2", BWTS_WIDE_SEG_LOG2="27", BWTS_WIDE_BUCKET=str(1 << 27))
+    proc = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+    out, _ = proc.communicate(timeout=900)
+    _wait_gpu_handle_released(proc.pid)
+    assert proc.returncode == 0 and b"wide ok" in out, out.decode()[-3000:]
+
+
+# ---------------------------------------------------------------------------------------------
 # repeat-rich text (SURVEY 8 f4; the reference's named workload is enwik8, Makefile:35-38)
 # ---------------------------------------------------------------------------------------------
 def test_text_generator_matches_oracle(ctx):
