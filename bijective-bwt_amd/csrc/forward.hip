@@ -290,45 +290,13 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
                         const double partners = m >= 8.0 ? (double)n * m / pairs : (double)n * share[b];   // few hits: trust the model
                         if (1.0 - exp(-partners) <= 1.0 / 64.0) { kb_emp = b; break; }
                     }
-                    bool long_repeats = false;
-                    if (kb_emp == 64) {
-                        // No width gets the ties down.  Short repeats (words) thin out steadily as the key grows and want the
-                        // full 64 bits; long repeats (copied stretches) tie their positions at every width alike -- the sample's
-                        // matches stop falling -- and then every key byte beyond that point is a radix pass spent on nothing.
-                        const double m56 = (double)ctx->h_small[CNT_SAMPLE + 4];
-                        for (int b = 32, w = 1; b <= 48; b += 8, w++) {
-                            const double m = (double)ctx->h_small[CNT_SAMPLE + w];
-                            if (m56 >= 8.0 && m <= 1.5 * m56 + 16.0) { kb_emp = b; long_repeats = true; break; }
-                        }
-                    }
-                    if (long_repeats) {
-                        // The rounds after round 0 will dominate, and their first step is the number of symbols EVERY key is
-                        // sure to cover (key bits / longest code word): a flatter tree -- longest code at most one bit above the
-                        // fixed width -- trades a little key entropy for a first step twice as long (one round less over
-                        // most of the input).
-                        double scale = 4.0;
-                        int lim = bits + 1 > 8 ? bits + 1 : 8;
-                        int l2 = lmax;
-                        u32 c2[256]; u8 n2[256];
-                        double avg2 = avg, ent2 = ent;
-                        while (l2 > lim && scale < 1e9) {
-                            l2 = build_alphabetic_code(ctx->h_small + SM_HIST, n, c2, n2, &avg2, &ent2, scale);
-                            scale *= 4.0;
-                        }
-                        if (l2 <= lim && l2 < lmax) {
-                            memcpy(vcode, c2, sizeof(c2)); memcpy(vlen, n2, sizeof(n2));
-                            lmax_eff = l2; avg = avg2;
-                        }
-                    }
                     if (kb_emp > kb) {
                         kb = kb_emp;
-                        if (!long_repeats) {
-                            // the fixed-width alternative was sized by the same model: let it use every symbol that fits
-                            al->msym = 64 / bits;
-                            al->key_bits = al->bits * al->msym;
-                            al->hstep = al->msym;
-                            al->patch_span = al->msym - 1;
-                        }
+                        // the fixed-width alternative was sized by the same model: let it use every symbol that fits
+                        al->msym = 64 / bits;
+                        al->key_bits = al->bits * al->msym;
+                        al->hstep = al->msym;
+                        al->patch_span = al->msym - 1;
                     }
                 }
             }
@@ -1393,7 +1361,6 @@ __global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restric
 #define DG_SPAN    (DG_THREADS * DG_ITEMS)            // list elements a workgroup looks at
 #define DG_OWN     (DG_SPAN - 2 * DG_CAP - 1)         // ... and decides: DG_CAP in front and DG_CAP + 1 behind are only looked at
 #define DG_FS_LDS  1024                  // factor starts kept in LDS when there are at most this many
-#define DG_ORDER_BITS 24                // bits of a group's smallest position the list is ordered by (dg_minpos_kernel)
 #define DG_CNT_BIG    8                 // counters[DG_CNT_BIG .. + DG_CNT_SPREAD): elements of larger groups, spread over many addresses
 #define DG_CNT_SPREAD 1024
 enum { DG_DONE = 0, DG_KEEP = 1, DG_BIG = 2, DG_MOVED = 4 };      // state: low bits = what happens to the element; DG_MOVED: its head (= rank) changed
@@ -1490,7 +1457,7 @@ __global__ __launch_bounds__(DG_THREADS) void dg_minpos_kernel(const u32 *__rest
             for (u32 m = 0; m < ds.sz[j]; m++) { const u32 q = pos[ds.gs[j] + m]; mn = q < mn ? q : mn; }
             sk = mn;
         } else sk = n + (u64)ds.h[j];
-        keys[e] = ((u64)ds.h[j] << DG_ORDER_BITS) | (kb > DG_ORDER_BITS ? sk >> (kb - DG_ORDER_BITS) : sk);
+        keys[e] = ((u64)ds.h[j] << kb) | sk;
         vals[e] = ds.idx[j];
     }
 }
@@ -1498,7 +1465,7 @@ __global__ __launch_bounds__(256) void dg_unpack_kernel(const u64 *__restrict__ 
                                                         u32 *__restrict__ idx, u32 *__restrict__ head)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> DG_ORDER_BITS); }
+    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> kb); }
 }
 
 // Workgroup w looks at list elements [w * DG_OWN - DG_CAP, ... + DG_SPAN): LDS slot sl <-> element e = w * DG_OWN - DG_CAP + sl,
@@ -1796,7 +1763,7 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     int nxt = 0;
     static const bool reorder_ok = [] { const char *e = getenv("BWTS_DENSE_ORDER"); return !(e && atoi(e) == 0); }();
     const int kb = bitlen_u64(2 * n - 1);
-    if (reorder_ok && a >= (1ull << 16)) {
+    if (reorder_ok && kb <= 32 && a >= (1ull << 16)) {
         // groups in the order of their smallest position (see dg_minpos_kernel); the sorted list lands in sets[0]
         char *ob = nullptr;
         const size_t a8 = align_up((size_t)a * 8, 256);
@@ -1810,12 +1777,10 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             dg_minpos_kernel<<<dim3((unsigned)((a + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a, n, kb, op.keys[0], op.vals[0]);
             HIPC(hipGetLastError());
         }
-        // the top 24 bits are what locality needs: groups whose smallest positions share a window of 2 n / 2^24 positions (64 at
-        // n = 2^30, one wave's worth) end up together, in their old relative order -- three passes instead of four.  (16 bits
-        // were measurably too coarse: a 16 K-position window is worked on by workgroups on several XCDs at once, each of
-        // which fetches the window's rank lines into its own L2.)
+        // (ordering by fewer bits was measured: 16 bits cost 30 ms more in the rounds than the two saved passes, 24 bits 25 ms more
+        // than the one saved pass -- consecutive groups have to touch consecutive ranks, not just nearby ones)
         int ores = 0;
-        BWTS_TRY(radix_sort_pairs(ctx, op, a, kb < DG_ORDER_BITS ? kb : DG_ORDER_BITS, &ores));
+        BWTS_TRY(radix_sort_pairs(ctx, op, a, kb, &ores));
         {
             SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
             dg_unpack_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(op.keys[ores], op.vals[ores], a, kb, sets[0].idx, sets[0].head);

@@ -195,8 +195,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     const u64 nseg = (n + seg - 1) / seg;
     const u64 tiles = scan_tiles(n);
     const u64 M = kn.bucket_cap;                                   // elements a bucket may hold
-    u64 tied_cap = n / 4 + 1024;                                   // elements the tied list may hold
-    if (tied_cap > WIDE_TIED_CAP) tied_cap = WIDE_TIED_CAP;
+    const u64 tied_cap = n < WIDE_TIED_CAP ? n : WIDE_TIED_CAP;    // elements the tied list may hold
     const u64 Mb = M > tied_cap ? M : tied_cap;                    // the buckets' sort buffers also serve the rounds over the tied list
     const u64 mwords = (Mb + 63) / 64 + 1;
     // ---- arena layout -------------------------------------------------------------------------------------------------
