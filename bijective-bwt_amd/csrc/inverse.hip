@@ -999,9 +999,13 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     return BWTS_OK;
 }
 
+#include "wide_inverse.h"
+
 int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
-    if (n > 0x100000000ull) return BWTS_E_RANGE;
+    // beyond 32-bit indices: the 64-bit form (wide_inverse.h); BWTS_FORCE_WIDE sends every input there (tests)
+    static const int force_wide = [] { const char *e = getenv("BWTS_FORCE_WIDE"); return e ? atoi(e) : 0; }();
+    if (n > 0x100000000ull || force_wide) return inverse_wide_impl(ctx, d_in, n, d_out);
     bool retry = false, ambiguous = false;
     // how visited entries are recorded: index log (default), or the two mark forms (BWTS_INV_MARK=sentinel|bytemap,
     // BWTS_BYTEMARK=1: tests, and the fallback chain below)

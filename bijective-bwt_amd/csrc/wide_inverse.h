@@ -1,0 +1,485 @@
+// wide_inverse.h -- inverse transform of inputs beyond the 32-bit index range (n > 2^32).  Included by inverse.hip.
+//
+// Same plan as the main path (unbwts.c:31-86 -> stable LF map, splitter walk that records every segment's symbols, ranking
+// of the reduced list, placement), with 64-bit element indices and without the main path's tuning: LF is a u64 array built
+// segment by segment (the tile table's offsets are 32-bit), visited entries are marked in a byte map, the reduced list
+// (n / 256 nodes) is ranked by plain pointer jumping, and everything sized by node or cycle counts carries 64-bit positions.
+// Memory at n = 12 GiB: LF 96 GiB + marks 12 + recorded segments 58 + nodes ~6.
+#define WI_G_LOG2 8
+#define WI_NIL 0xffffffffu
+
+__device__ __forceinline__ u32 symbol_of64(const u64 *Ctab, u64 y)
+{
+    u32 lo = 0, hi = 255;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const u32 mid = (lo + hi + 1) >> 1;
+        if (Ctab[mid] <= y) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// LF[p0 + i] for one segment: the segment's scanned tile table gives the rank inside the segment (32-bit), base64[c] turns it
+// into the global one: C[c] + occurrences of c in earlier segments - first slot of c in the segment's own table
+__global__ __launch_bounds__(LF_THREADS) void lf_rank_wide_kernel(const u8 *__restrict__ B, u64 count, const u32 *__restrict__ tile_off,
+                                                                  const u64 *__restrict__ base64, u64 *__restrict__ LF)
+{
+    __shared__ u32 whist[LF_WAVES][256];
+    __shared__ u64 sbase[256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const u64 wave_base = (u64)blockIdx.x * LF_TILE + (u64)w * (64 * LF_ITEMS);
+    for (int i = tid; i < LF_WAVES * 256; i += LF_THREADS) ((u32 *)whist)[i] = 0;
+    sbase[tid] = base64[tid];
+    u32 sym[LF_ITEMS], rnk[LF_ITEMS];
+#pragma unroll
+    for (int j = 0; j < LF_ITEMS; j++) {
+        const u64 i = wave_base + (u64)j * 64 + lane;
+        sym[j] = i < count ? (u32)B[i] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < LF_ITEMS; j++) {
+        const bool valid = wave_base + (u64)j * 64 + lane < count;
+        const u64 peers = match_digit8(sym[j], valid);
+        const u32 before = (u32)__popcll(peers & lanemask_lt());
+        const u32 cnt = (u32)__popcll(peers);
+        const u32 prev = whist[w][sym[j]];
+        rnk[j] = prev + before;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid && before == 0) whist[w][sym[j]] = prev + cnt;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    __syncthreads();
+    {
+        u32 run = tile_off[(u64)blockIdx.x * 256 + tid];
+#pragma unroll
+        for (int ww = 0; ww < LF_WAVES; ww++) {
+            const u32 c = whist[ww][tid];
+            whist[ww][tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < LF_ITEMS; j++) {
+        const u64 i = wave_base + (u64)j * 64 + lane;
+        if (i < count) LF[i] = sbase[sym[j]] + (u64)(whist[w][sym[j]] + rnk[j]);
+    }
+}
+
+// node record: where the walk went next, how many symbols it recorded, the smallest element it saw and where
+struct WiNode { u32 nxt, len; u64 mn; u32 off, pad; };
+
+// walk_record_kernel of the main path with 64-bit elements and byte-map marks (see there for the scheme)
+__global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__restrict__ LF, u8 *__restrict__ marks, u64 s, u64 node_cap, u32 slot,
+                                                               const u64 *__restrict__ Cg, u8 *__restrict__ seg, WiNode *__restrict__ nodes,
+                                                               unsigned long long *__restrict__ ticket, unsigned long long *__restrict__ vcount,
+                                                               unsigned long long *__restrict__ overflow)
+{
+    __shared__ u64 Ctab[257];
+    for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
+    __syncthreads();
+    const u64 gmask = (1ull << WI_G_LOG2) - 1ull;
+    bool have = false, done = false;
+    u64 my = 0, x = 0, mn = 0;
+    u32 len = 0, mnoff = 0;
+    u32 sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;
+    u64 bnext = 0, bend = 0;
+    bool exhausted = false;
+    for (;;) {
+        const u64 need = __ballot(!have && !done);
+        if (need) {
+            if (bnext == bend && !exhausted) {
+                const int leader = __ffsll((unsigned long long)need) - 1;
+                unsigned long long basev = 0;
+                if (lane_id() == leader) basev = atomicAdd(ticket, (unsigned long long)WALK_BATCH);
+                basev = shfl_t((u64)basev, leader);
+                bnext = basev;
+                bend = basev + WALK_BATCH < s ? basev + WALK_BATCH : s;
+                if (basev >= s) { exhausted = true; bnext = bend = 0; }
+            }
+            if (!have && !done) {
+                const u64 id = bnext + (u64)__popcll(need & lanemask_lt());
+                if (id < bend) { have = true; my = id; x = my << WI_G_LOG2; len = 0; mn = x; mnoff = 0; sb0 = sb1 = sb2 = sb3 = 0; }
+                else if (exhausted) done = true;
+            }
+            const u64 taken = bnext + (u64)__popcll(need);
+            bnext = taken < bend ? taken : bend;
+        }
+        if (__ballot(have || !done) == 0) break;
+        if (have) {
+            const u64 y = LF[x];
+            marks[x] = 1;
+            {
+                const u32 sh = symbol_of64(Ctab, y) << (8 * (len & 3u));
+                const u32 w = (len >> 2) & 3u;
+                sb0 |= w == 0 ? sh : 0u; sb1 |= w == 1 ? sh : 0u; sb2 |= w == 2 ? sh : 0u; sb3 |= w == 3 ? sh : 0u;
+            }
+            if ((len & 15u) == 15u) {
+                *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);
+                sb0 = sb1 = sb2 = sb3 = 0;
+            }
+            len++;
+            x = y;
+            const bool at_splitter = (x & gmask) == 0;
+            if (at_splitter || len == slot) {
+                if (len & 15u) *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);
+                u64 next_node;
+                if (at_splitter) { next_node = x >> WI_G_LOG2; have = false; }
+                else {
+                    next_node = s + atomicAdd(vcount, 1ull);
+                    if (next_node >= node_cap) { atomicAdd(overflow, 1ull); next_node = node_cap - 1; }
+                }
+                WiNode nd; nd.nxt = (u32)next_node; nd.len = len; nd.mn = mn; nd.off = mnoff; nd.pad = 0;
+                nodes[my] = nd;
+                if (!at_splitter) { my = next_node; len = 0; mn = x; mnoff = 0; sb0 = sb1 = sb2 = sb3 = 0; }
+            } else if (x < mn) { mn = x; mnoff = len; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void collect_unvisited_wide_kernel(const u64 *__restrict__ LF, const u8 *__restrict__ marks, u64 n,
+                                                                     u64 *__restrict__ uidx, u64 *__restrict__ ulf, u64 cap, unsigned long long *__restrict__ count)
+{
+    for (u64 base = (u64)blockIdx.x * 256; base < n; base += (u64)gridDim.x * 256) {
+        const u64 i = base + threadIdx.x;
+        const bool un = i < n && marks[i] == 0;
+        const u64 m = __ballot(un);
+        if (m) {
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            unsigned long long b = 0;
+            if (lane_id() == leader) b = atomicAdd(count, (unsigned long long)__popcll(m));
+            b = shfl_t((u64)b, leader);
+            if (un) { const u64 at = b + (u64)__popcll(m & lanemask_lt()); if (at < cap) { uidx[at] = i; ulf[at] = LF[i]; } }
+        }
+    }
+}
+
+// pointer jumping over the nodes: records (leader, hop, smallest element) and (sum of lengths, hop)
+struct WiMin { u32 leader, hop; u64 mn; };
+struct WiSum { u64 sum; u32 hop, pad; };
+struct WiCycle { u64 minelem, len; u32 leader, pad; };
+
+__global__ __launch_bounds__(256) void wi_init_kernel(u64 s, const WiNode *__restrict__ nodes, WiMin *__restrict__ rec)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v < s) { WiMin r; r.leader = (u32)v; r.hop = nodes[v].nxt; r.mn = nodes[v].mn; rec[v] = r; }
+}
+__global__ __launch_bounds__(256) void wi_jump_min_kernel(u64 s, const WiMin *__restrict__ in, WiMin *__restrict__ out)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= s) return;
+    const WiMin a = in[v], b = in[a.hop];
+    WiMin r; r.leader = a.leader < b.leader ? a.leader : b.leader; r.mn = a.mn < b.mn ? a.mn : b.mn; r.hop = b.hop;
+    out[v] = r;
+}
+__global__ __launch_bounds__(256) void wi_cut_kernel(u64 s, const WiNode *__restrict__ nodes, const WiMin *__restrict__ rec, WiSum *__restrict__ sh)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v < s) { WiSum r; r.sum = nodes[v].len; r.hop = nodes[v].nxt == rec[v].leader ? WI_NIL : nodes[v].nxt; r.pad = 0; sh[v] = r; }
+}
+__global__ __launch_bounds__(256) void wi_jump_sum_kernel(u64 s, const WiSum *__restrict__ in, WiSum *__restrict__ out)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= s) return;
+    const WiSum a = in[v];
+    if (a.hop == WI_NIL) out[v] = a;
+    else { const WiSum b = in[a.hop]; WiSum r; r.sum = a.sum + b.sum; r.hop = b.hop; r.pad = 0; out[v] = r; }
+}
+__global__ __launch_bounds__(256) void wi_finish_kernel(u64 s, const WiMin *__restrict__ rec, const WiSum *__restrict__ sh, const WiNode *__restrict__ nodes,
+                                                        u64 *__restrict__ dist, u64 *__restrict__ min_dist, WiCycle *__restrict__ cyc,
+                                                        unsigned long long *__restrict__ ncyc)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= s) return;
+    const WiMin r = rec[v];
+    const u64 L = sh[r.leader].sum, d = L - sh[v].sum;
+    dist[v] = d;
+    if (nodes[v].mn == r.mn) min_dist[r.leader] = d + nodes[v].off;
+    if (r.leader == (u32)v) {
+        const unsigned long long at = atomicAdd(ncyc, 1ull);
+        WiCycle c; c.minelem = r.mn; c.len = L; c.leader = r.leader; c.pad = 0;
+        cyc[at] = c;
+    }
+}
+// cycles without a splitter (tiny_cycle_scan_kernel of the main path)
+__global__ __launch_bounds__(256) void tiny_cycle_scan_wide_kernel(const u64 *__restrict__ uidx, const u64 *__restrict__ ulf, u64 nu, const u64 *__restrict__ LF,
+                                                                   u32 cap, WiCycle *__restrict__ cyc, unsigned long long *__restrict__ count,
+                                                                   unsigned long long *__restrict__ overflow)
+{
+    const u64 q = (u64)blockIdx.x * 256 + threadIdx.x;
+    bool ismin = false;
+    u64 x = 0, len = 1;
+    if (q < nu) {
+        x = uidx[q];
+        u64 y = ulf[q];
+        ismin = true;
+        while (y != x) {
+            if (y < x) { ismin = false; break; }
+            y = LF[y];
+            if (++len > cap) { atomicAdd(overflow, 1ull); ismin = false; break; }
+        }
+    }
+    const u64 m = __ballot(ismin);
+    if (m == 0) return;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    unsigned long long b = 0;
+    if (lane_id() == leader) b = atomicAdd(count, (unsigned long long)__popcll(m));
+    b = shfl_t((u64)b, leader);
+    if (ismin) { WiCycle c; c.minelem = x; c.len = len; c.leader = WI_NIL; c.pad = 0; cyc[b + (u64)__popcll(m & lanemask_lt())] = c; }
+}
+__global__ __launch_bounds__(256) void wi_cycle_keys_kernel(const WiCycle *__restrict__ cyc, u64 m, u64 *__restrict__ keys, u32 *__restrict__ vals)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) { keys[i] = cyc[i].minelem; vals[i] = (u32)i; }
+}
+struct WiLenIn {
+    const WiCycle *cyc; const u32 *order;
+    __device__ __forceinline__ u64 operator()(u64 j) const { return cyc[order[j]].len; }
+};
+struct WiEndOut {
+    const WiCycle *cyc; const u32 *order; u64 m; u64 last; u64 *end_by_leader; u64 *end_of_cyc; u64 *total;
+    __device__ __forceinline__ void operator()(u64 j, u64 used) const
+    {
+        const u32 i = order[j];
+        const WiCycle c = cyc[i];
+        const u64 end = last - used;
+        if (c.leader != WI_NIL) end_by_leader[c.leader] = end;
+        end_of_cyc[i] = end;
+        if (j + 1 == m) *total = used + c.len;
+    }
+};
+// node -> text position of its first symbol, symbols until the walk passes the cycle's smallest element, cycle length
+__global__ __launch_bounds__(256) void wi_place_kernel(u64 s, const WiMin *__restrict__ rec, const WiSum *__restrict__ sh, const u64 *__restrict__ dist,
+                                                       const u64 *__restrict__ min_dist, const u64 *__restrict__ end_by_leader,
+                                                       u64 *__restrict__ opos, u64 *__restrict__ wrap_at, u64 *__restrict__ cyc_len)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= s) return;
+    const u32 l = rec[v].leader;
+    const u64 L = sh[l].sum, dm = min_dist[l], d = dist[v];
+    const u64 t = d >= dm ? d - dm : d + L - dm;
+    opos[v] = end_by_leader[l] - t;
+    wrap_at[v] = L - t;
+    cyc_len[v] = L;
+}
+__global__ __launch_bounds__(256) void place_segments_wide_kernel(const u8 *__restrict__ seg, u64 nodes_n, u32 slot, int tpn_log2, const WiNode *__restrict__ nodes,
+                                                                  const u64 *__restrict__ opos, const u64 *__restrict__ wrap_at, const u64 *__restrict__ cyc_len,
+                                                                  u8 *__restrict__ out)
+{
+    const u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const u64 v = gid >> tpn_log2;
+    if (v >= nodes_n) return;
+    const u32 sub = (u32)(gid & ((1ull << tpn_log2) - 1ull)), tpn = 1u << tpn_log2;
+    const u32 len = nodes[v].len;
+    const u64 o = opos[v], wr = wrap_at[v], L = cyc_len[v];
+    const u8 *src = seg + v * slot;
+    for (u32 c = sub * 16; c < len; c += tpn * 16) {
+        if (c + 16 <= len && ((u64)c + 16 <= wr || (u64)c >= wr)) {
+            const uint4 q = *(const uint4 *)(src + c);
+            const u64 base = (u64)c >= wr ? o - c + L : o - c;
+            Unaligned16 r;
+            r.w[0] = __builtin_bswap32(q.w); r.w[1] = __builtin_bswap32(q.z);
+            r.w[2] = __builtin_bswap32(q.y); r.w[3] = __builtin_bswap32(q.x);
+            *(Unaligned16 *)(out + base - 15) = r;
+        } else {
+            const u32 e = c + 16 < len ? c + 16 : len;
+            for (u32 i = c; i < e; i++) out[(u64)i >= wr ? o - i + L : o - i] = src[i];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void tiny_place_wide_kernel(const WiCycle *__restrict__ cyc, u64 m, const u64 *__restrict__ end_of_cyc,
+                                                              const u64 *__restrict__ LF, const u64 *__restrict__ Cg, u8 *__restrict__ out)
+{
+    __shared__ u64 Ctab[257];
+    for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
+    __syncthreads();
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const WiCycle c = cyc[i];
+    if (c.leader != WI_NIL) return;
+    u64 x = c.minelem, pos = end_of_cyc[i];
+    for (u64 t = 0; t < c.len; t++) {
+        const u64 y = LF[x];
+        out[pos--] = (u8)symbol_of64(Ctab, y);
+        x = y;
+    }
+}
+
+static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
+{
+    if (n > (1ull << 36)) return BWTS_E_RANGE;
+    const u64 G = 1ull << WI_G_LOG2;
+    const u64 s = (n + G - 1) / G;
+    const u32 slot = (u32)(4 * G);
+    const u64 node_cap = s + s / 8 + 1024;
+    if (node_cap > 0xfffffff0ull) return BWTS_E_RANGE;
+    int seg_log2 = 31;
+    if (const char *e = getenv("BWTS_WIDE_SEG_LOG2")) { const int v = atoi(e); if (v >= 12 && v <= 31) seg_log2 = v; }
+    const u64 segn = 1ull << seg_log2;
+    const u64 nseg = (n + segn - 1) / segn;
+    const size_t need = align_up(n * 8, 256) + align_up(n, 256) + align_up(node_cap * slot, 256) + align_up(node_cap * sizeof(WiNode), 256) +
+                        2 * align_up(node_cap * sizeof(WiMin), 256) + 2 * align_up(node_cap * sizeof(WiSum), 256) + 6 * align_up(node_cap * 8, 256) +
+                        align_up(node_cap * sizeof(WiCycle), 256) + radix_tile_hist_bytes(segn) + scan_temp_bytes(segn) + (1 << 16);
+    BWTS_TRY(arena_reserve(ctx, need));
+    u64 *LF = arena_array<u64>(ctx, n);
+    u8 *marks = arena_array<u8>(ctx, n);
+    u8 *seg = arena_array<u8>(ctx, node_cap * slot);
+    WiNode *nodes = arena_array<WiNode>(ctx, node_cap);
+    WiMin *wmin[2] = {arena_array<WiMin>(ctx, node_cap), arena_array<WiMin>(ctx, node_cap)};
+    WiSum *wsum[2] = {arena_array<WiSum>(ctx, node_cap), arena_array<WiSum>(ctx, node_cap)};
+    u64 *dist = arena_array<u64>(ctx, node_cap), *min_dist = arena_array<u64>(ctx, node_cap), *end_by_leader = arena_array<u64>(ctx, node_cap);
+    u64 *opos = arena_array<u64>(ctx, node_cap), *wrap_at = arena_array<u64>(ctx, node_cap), *cyc_len = arena_array<u64>(ctx, node_cap);
+    WiCycle *ncyc = arena_array<WiCycle>(ctx, node_cap);
+    u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(segn));
+    void *scan_temp = arena_alloc(ctx, scan_temp_bytes(segn));
+    if (!LF || !marks || !seg || !nodes || !wmin[1] || !wsum[1] || !dist || !min_dist || !end_by_leader || !opos || !wrap_at || !cyc_len || !ncyc ||
+        !tile_hist || !scan_temp)
+        return BWTS_E_NOMEM;
+
+    // symbol boundaries C (unbwts.c:34-43), 64-bit
+    u64 *dC = ctx->d_small + 1024, *hC = ctx->h_small + 1024;
+    u64 *dBase = ctx->d_small + 1536, *hBase = ctx->h_small + 1536;
+    u64 *dHist = ctx->d_small + 2048, *hHist = ctx->h_small + 2048;
+    BWTS_TRY(byte_histogram_device(ctx, d_in, n, dHist));
+    BWTS_TRY(read_small(ctx, 2048, 256));
+    {
+        u64 run = 0;
+        for (int c = 0; c < 256; c++) { hC[c] = run; run += hHist[c]; }
+        hC[256] = n;
+        if (run != n) return BWTS_E_INTERNAL;
+    }
+    HIPC(hipMemcpyAsync(dC, hC, 257 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    // stable LF map (unbwts.c:50-52), segment by segment
+    u64 before[256];
+    for (int c = 0; c < 256; c++) before[c] = 0;
+    for (u64 sg = 0; sg < nseg; sg++) {
+        const u64 p0 = sg * segn, c = n - p0 < segn ? n - p0 : segn;
+        const u64 tiles = (c + LF_TILE - 1) / LF_TILE;
+        SpanGuard g(ctx, BWTS_K_LF_BUILD, c, 10 * c);
+        BWTS_TRY(byte_histogram_device(ctx, d_in + p0, c, dHist));
+        BWTS_TRY(read_small(ctx, 2048, 256));
+        {
+            u64 run = 0;
+            for (int q = 0; q < 256; q++) { hBase[q] = hC[q] + before[q] - run; run += hHist[q]; before[q] += hHist[q]; }
+        }
+        HIPC(hipMemcpyAsync(dBase, hBase, 256 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        lf_hist_kernel<<<dim3((unsigned)tiles), dim3(LF_THREADS), 0, ctx->stream>>>(d_in + p0, c, tile_hist);
+        BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, scan_temp));
+        lf_rank_wide_kernel<<<dim3((unsigned)tiles), dim3(LF_THREADS), 0, ctx->stream>>>(d_in + p0, c, tile_hist, dBase, LF + p0);
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(ctx->stream));            // hBase is rewritten by the next segment
+    }
+
+    unsigned long long *ticket = (unsigned long long *)(ctx->d_small + SMI_COUNTERS);
+    HIPC(hipMemsetAsync(ticket, 0, 16 * sizeof(u64), ctx->stream));
+    HIPC(hipMemsetAsync(marks, 0, n, ctx->stream));
+    {
+        SpanGuard sg(ctx, BWTS_K_WALK, n, 10 * n);
+        const u64 walkers = s < 524288 ? s : 524288;
+        walk_record_wide_kernel<<<dim3((unsigned)((walkers + 255) / 256)), dim3(256), 0, ctx->stream>>>(LF, marks, s, node_cap, slot, dC, seg, nodes, ticket,
+                                                                                                       ticket + 3, ticket + 4);
+        HIPC(hipGetLastError());
+    }
+    BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
+    if (ctx->h_small[SMI_COUNTERS + 4]) return BWTS_E_NOMEM;          // node pool exhausted (adversarial LF): no fallback in the wide form
+    const u64 s_all = s + ctx->h_small[SMI_COUNTERS + 3];
+
+    // elements in cycles without a splitter
+    u64 ucap = ctx->unv_hint > (1ull << 20) ? ctx->unv_hint : (1ull << 20);
+    if (ucap > n) ucap = n;
+    u64 *uidx = nullptr, *ulf = nullptr, *end_of_cyc = nullptr;
+    WiCycle *cyc = nullptr;
+    auto lay_out = [&](u64 cap) -> int {
+        char *ub = nullptr;
+        const size_t e8 = align_up((size_t)cap * 8, 256), c24 = align_up((size_t)(node_cap + cap) * sizeof(WiCycle), 256),
+                     c8 = align_up((size_t)(node_cap + cap) * 8, 256);
+        BWTS_TRY(aux_reserve_slot(ctx, 0, 2 * e8 + c24 + c8, &ub));
+        uidx = (u64 *)ub; ulf = (u64 *)(ub + e8);
+        cyc = (WiCycle *)(ub + 2 * e8);
+        end_of_cyc = (u64 *)(ub + 2 * e8 + c24);
+        return BWTS_OK;
+    };
+    BWTS_TRY(lay_out(ucap));
+    auto collect = [&]() -> int {
+        SpanGuard sg(ctx, BWTS_K_OTHER, n, n);
+        u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+        collect_unvisited_wide_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, ucap, ticket + 1);
+        HIPC(hipGetLastError());
+        return BWTS_OK;
+    };
+    BWTS_TRY(collect());
+    // pointer jumping over the nodes
+    const int R = [&] { int b = 0; for (u64 x = s_all; x; x >>= 1) b++; return b; }();
+    int cur = 0, sc = 0;
+    {
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, s_all, 0);
+        const int gb = grid1(s_all);
+        wi_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nodes, wmin[0]);
+        for (int r = 0; r < R; r++, cur ^= 1) wi_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, wmin[cur], wmin[cur ^ 1]);
+        wi_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, nodes, wmin[cur], wsum[0]);
+        for (int r = 0; r < R; r++, sc ^= 1) wi_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, wsum[sc], wsum[sc ^ 1]);
+        wi_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(s_all, wmin[cur], wsum[sc], nodes, dist, min_dist, ncyc, ticket + 2);
+        HIPC(hipGetLastError());
+    }
+    BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
+    const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
+    const u64 kc = ctx->h_small[SMI_COUNTERS + 2];
+    ctx->tm.unvisited = nu;
+    ctx->unv_hint = (size_t)nu;
+    if (nu > n || kc == 0 || kc > s_all) return BWTS_E_INTERNAL;
+    if (nu > ucap) {
+        ucap = nu;
+        BWTS_TRY(lay_out(ucap));
+        HIPC(hipMemsetAsync(ticket + 1, 0, sizeof(u64), ctx->stream));
+        BWTS_TRY(collect());
+    }
+    if (nu) {
+        SpanGuard sg(ctx, BWTS_K_OTHER, nu, 16 * nu);
+        u64 cap = (1ull << 36) / nu;
+        if (cap > 64 * G) cap = 64 * G;
+        if (cap < 4 * G) cap = 4 * G;
+        tiny_cycle_scan_wide_kernel<<<dim3(grid1(nu)), dim3(256), 0, ctx->stream>>>(uidx, ulf, nu, LF, (u32)cap, cyc, ticket + 7, ticket + 4);
+        HIPC(hipGetLastError());
+    }
+    BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
+    const u64 kt = ctx->h_small[SMI_COUNTERS + 7];
+    if (ctx->h_small[SMI_COUNTERS + 4]) return BWTS_E_RANGE;          // a cycle without a splitter too long for one lane
+    if (kt > nu) return BWTS_E_INTERNAL;
+    const u64 kall = kc + kt;
+    ctx->tm.factors = kall;
+    {
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, kall, 0);
+        HIPC(hipMemcpyAsync(cyc + kt, ncyc, kc * sizeof(WiCycle), hipMemcpyDeviceToDevice, ctx->stream));
+        char *sb = nullptr;
+        const size_t k8 = align_up(kall * 8, 256), k4 = align_up(kall * 4, 256);
+        BWTS_TRY(aux_reserve_slot(ctx, 1, 2 * k8 + 2 * k4 + radix_tile_hist_bytes(kall) + scan_temp_bytes(kall) + 4096, &sb));
+        SortPlan cp;
+        cp.keys[0] = (u64 *)sb; cp.keys[1] = (u64 *)(sb + k8);
+        cp.vals[0] = (u32 *)(sb + 2 * k8); cp.vals[1] = (u32 *)(sb + 2 * k8 + k4);
+        cp.tile_hist = (u32 *)(sb + 2 * k8 + 2 * k4);
+        cp.scan_temp = sb + 2 * k8 + 2 * k4 + radix_tile_hist_bytes(kall);
+        wi_cycle_keys_kernel<<<dim3(grid1(kall)), dim3(256), 0, ctx->stream>>>(cyc, kall, cp.keys[0], cp.vals[0]);
+        int res = 0, kbits = 0;
+        for (u64 x = n - 1; x; x >>= 1) kbits++;
+        BWTS_TRY(radix_sort_pairs(ctx, cp, kall, kbits < 1 ? 1 : kbits, &res));
+        WiLenIn lin{cyc, cp.vals[res]};
+        WiEndOut lout{cyc, cp.vals[res], kall, n - 1, end_by_leader, end_of_cyc, ctx->d_small + SMI_COUNTERS + 13};
+        BWTS_TRY((device_scan<false, u64>(ctx, kall, lin, lout, OpAdd(), (u64)0, cp.scan_temp)));
+        wi_place_kernel<<<dim3(grid1(s_all)), dim3(256), 0, ctx->stream>>>(s_all, wmin[cur], wsum[sc], dist, min_dist, end_by_leader, opos, wrap_at, cyc_len);
+        HIPC(hipGetLastError());
+    }
+    {
+        SpanGuard sg(ctx, BWTS_K_WALK_EMIT, n, 2 * n);
+        const int tpn_log2 = WI_G_LOG2 - 4;
+        const u64 threads = s_all << tpn_log2;
+        place_segments_wide_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(seg, s_all, slot, tpn_log2, nodes, opos, wrap_at, cyc_len,
+                                                                                                           d_out);
+        if (kt) tiny_place_wide_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(cyc, kt, end_of_cyc, LF, dC, d_out);
+        HIPC(hipGetLastError());
+    }
+    BWTS_TRY(read_small(ctx, SMI_COUNTERS + 13, 1));
+    if (ctx->h_small[SMI_COUNTERS + 13] != n) return BWTS_E_INTERNAL;
+    return BWTS_OK;
+}

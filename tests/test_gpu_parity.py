@@ -561,15 +561,17 @@ def _lf_walk_matches_text(x, y, steps):
     return steps
 
 
-def test_wide_12GiB_dna_properties(ctx, pkg):
-    """dna(12 GiB): beyond 2^32 positions.  No inverse exists at this size yet, so: the bytes are a permutation of the input's,
-    bwts[0] = T[n-1] (mk_bwts_sa.c:188), and 200 000 steps of the inverse's LF walk from slot 0 -- done on the host -- read the
-    text backwards from its end exactly (one misplaced byte anywhere shifts the ranks behind it and derails the walk)."""
+def test_wide_12GiB_dna_round_trip(ctx, pkg):
+    """dna(12 GiB): beyond 2^32 positions, forward and inverse through the 64-bit paths.  Round trip exact (compared on the host);
+    the bytes are a permutation of the input's, bwts[0] = T[n-1] (mk_bwts_sa.c:188), and 200 000 steps of the inverse's LF walk
+    from slot 0 -- done on the host with exact ranks, independently of the engine's inverse -- read the text backwards from its
+    end (a sampled check of the forward bytes: each step tests one slot)."""
     n = 12 << 30
     try:
         d_in, d_out = ctx.alloc(n), ctx.alloc(n)
     except pkg.BwtsError:
         pytest.skip("not enough device memory")
+    d_back = None
     try:
         ctx.generate("dna", 1, n, d_in)
         try:
@@ -579,17 +581,27 @@ def test_wide_12GiB_dna_properties(ctx, pkg):
                 pytest.skip("not enough free device memory for the 12 GiB case")
             raise
         t = ctx.timings()
-        x, y = d_in.download(), d_out.download()
-    finally:
+        x = d_in.download()
         d_in.free()
-        d_out.free()
+        y = d_out.download()
+        d_back = ctx.alloc(n)
+        ctx.inverse_device(d_out, n, d_back)
+        ti = ctx.timings()
+        back = d_back.download()
+    finally:
+        for b in (d_in, d_out, d_back):
+            if b is not None:
+                b.free()
+    assert np.array_equal(back, x)                               # unbwts o mk_bwts = id at 12 GiB
+    del back
     assert y[0] == x[-1]
     assert np.array_equal(O.generate("dna", 4096, 1, off=n - 4096), x[-4096:])
     hx = sum(np.bincount(x[i:i + (1 << 30)], minlength=256) for i in range(0, n, 1 << 30))
     hy = sum(np.bincount(y[i:i + (1 << 30)], minlength=256) for i in range(0, n, 1 << 30))
     assert np.array_equal(hx, hy)
     assert _lf_walk_matches_text(x, y, 200000) == 200000
-    assert t.factors >= 1 and t.rounds >= 1
+    assert t.factors >= 1 and t.rounds >= 1 and ti.factors == t.factors     # LF cycles = Lyndon factors
+    print("12 GiB: forward %.0f ms, inverse %.0f ms, factors %d" % (t.total_ms, ti.total_ms, t.factors))
 
 
 def test_lf_walk_checker_on_small_input():
