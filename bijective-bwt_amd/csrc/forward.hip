@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
                                                                  const u32 *__restrict__ fstart, u64 k,
                                                                  u32 *__restrict__ oidx, u32 *__restrict__ ohead, u8 *__restrict__ state,
                                                                  PrevSym prev, u8 *__restrict__ out /* null: no emission */,
-                                                                 unsigned long long *__restrict__ counters)
+                                                                 unsigned long long *__restrict__ counters, u32 *__restrict__ tile_big)
 {
     __shared__ u32 hd[DG_SPAN];              // group heads
     __shared__ u32 key[DG_SPAN];             // successor ranks of the members of the groups this workgroup orders
@@ -1558,6 +1558,7 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
     if (split_here) any_split = 1;
     __syncthreads();
     if (tid == 0) {
+        tile_big[blockIdx.x] = cnt_big;          // where the larger groups' elements are: their path then costs by their number, not by the list's
         // (one shared counter cost ~75 ns per workgroup: device-scope atomics on one address serialise across the XCDs)
         if (cnt_big) atomicAdd(&counters[DG_CNT_BIG + (blockIdx.x & (DG_CNT_SPREAD - 1))], (unsigned long long)cnt_big);
         if (any_split && __hip_atomic_load(&counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
@@ -1565,28 +1566,41 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
     }
 }
 
-// larger groups: compaction with the successor-rank gather.  Scan value: low word = flagged elements, high word = flagged
-// groups (their first elements) before the position; the compacted key carries the group's ordinal among the flagged groups
-// and the successor rank.
-struct DgBigIn {
-    const u8 *state; const u32 *head;
-    __device__ __forceinline__ u64 operator()(u64 i) const
-    {
-        const u32 f = (state[i] & 3) == DG_BIG ? 1u : 0u;
-        const u32 st = f && (i == 0 || head[i] != head[i - 1] || (state[i - 1] & 3) != DG_BIG) ? 1u : 0u;
-        return ((u64)st << 32) | f;
+// larger groups.  dense_round_kernel left, per workgroup, how many elements of its range it flagged (tile_big, scanned into
+// offsets): dg_big_collect_kernel lists the flagged elements' list indices in order, touching only ranges that hold any, and
+// the rest of the path runs over that list -- group ordinals by a scan, successor-rank gather, (ordinal, rank) keys.
+__global__ __launch_bounds__(256) void dg_big_collect_kernel(const u8 *__restrict__ state, u64 a, const u32 *__restrict__ tile_off, u32 *__restrict__ bigidx)
+{
+    __shared__ u32 scan_sm[4];
+    const u32 lo = tile_off[blockIdx.x], cnt = tile_off[blockIdx.x + 1] - lo;
+    if (cnt == 0) return;
+    const u64 e0 = (u64)blockIdx.x * DG_OWN;
+    u32 f[4], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                                     // blocked: 4 consecutive elements per thread (4 * 256 >= DG_OWN)
+        const u32 r = threadIdx.x * 4 + j;
+        const u64 e = e0 + r;
+        f[j] = (r < DG_OWN && e < a && (state[e] & 3) == DG_BIG) ? 1u : 0u;
+        mine += f[j];
     }
+    u32 total;
+    u32 at = lo + block_scan_exclusive<u32, OpAdd, 4>(mine, OpAdd(), 0u, scan_sm, &total);
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (f[j]) bigidx[at++] = (u32)(e0 + threadIdx.x * 4 + j);
+}
+struct DgBigIn {
+    const u32 *bigidx; const u32 *head;
+    __device__ __forceinline__ u32 operator()(u64 j) const { return (j == 0 || head[bigidx[j]] != head[bigidx[j - 1]]) ? 1u : 0u; }
 };
 template <bool CYCLIC>
 struct DgBigOut {
-    const u8 *state; const u32 *head; const u32 *idx; u64 a; int rb; const u32 *rank; u64 n; u64 h; const u32 *fstart; u64 k;
-    u64 *bk; u32 *bv; u32 *bpos;
-    __device__ __forceinline__ void operator()(u64 i, u64 before) const
+    const u32 *bigidx; const u32 *head; const u32 *idx; int rb; const u32 *rank; u64 n; u64 h; const u32 *fstart; u64 k;
+    u64 *bk; u32 *bv;
+    __device__ __forceinline__ void operator()(u64 j, u32 before) const
     {
-        if ((state[i] & 3) != DG_BIG) return;
-        const u32 st = (i == 0 || head[i] != head[i - 1] || (state[i - 1] & 3) != DG_BIG) ? 1u : 0u;
-        const u64 ord = (before >> 32) + st - 1;
-        const u32 at = (u32)before;
+        const u32 i = bigidx[j];
+        const u32 st = (j == 0 || head[i] != head[bigidx[j - 1]]) ? 1u : 0u;
+        const u64 ord = (u64)before + st - 1;
         const u64 p = idx[i];
         u64 r2;
         if (CYCLIC) {
@@ -1597,9 +1611,8 @@ struct DgBigOut {
             const u64 q = p + h;
             r2 = q < n ? (u64)rank[q] + 1ull : 0ull;
         }
-        bk[at] = (ord << rb) | r2;
-        bv[at] = (u32)p;
-        bpos[at] = (u32)i;
+        bk[j] = (ord << rb) | r2;
+        bv[j] = (u32)p;
     }
 };
 // regrouping of the sorted larger groups.  Scan value (max on both halves): high word = 1 + index of the element's group
@@ -1747,7 +1760,9 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u64 *cnt = ctx->d_small + SM_DGCNT;
     const size_t e4 = align_up((size_t)a * 4, 256), e1 = align_up((size_t)a, 256);
     char *base = nullptr;
-    BWTS_TRY(aux_reserve(ctx, 6 * e4 + e1, &base));
+    const size_t tb4 = align_up(((size_t)a / DG_OWN + 3) * 4, 256);
+    BWTS_TRY(aux_reserve(ctx, 6 * e4 + e1 + tb4, &base));
+    u32 *tile_big = (u32 *)(base + 6 * e4 + e1);
     u32 *t_idx = (u32 *)base, *t_head = (u32 *)(base + e4);
     u8 *state = (u8 *)(base + 2 * e4);
     ActiveList sets[2];
@@ -1792,11 +1807,12 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     for (u64 h = (u64)al.hstep;; h <<= 1) {
         rounds++;
         HIPC(hipMemsetAsync(cnt, 0, (DG_CNT_BIG + DG_CNT_SPREAD) * sizeof(u64), ctx->stream));
+        const u64 rtiles = (a + DG_OWN - 1) / DG_OWN;
+        HIPC(hipMemsetAsync(tile_big + rtiles, 0, sizeof(u32), ctx->stream));      // the scan below turns counts into offsets; entry [rtiles] = total
         {
             SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 29 * a);       // idx, head in; idx, head, state out; one rank gather
-            const unsigned blocks = (unsigned)((a + DG_OWN - 1) / DG_OWN);
-            dense_round_kernel<CYCLIC><<<dim3(blocks), dim3(DG_THREADS), 0, ctx->stream>>>(
-                cur.idx, cur.head, a, sp.rank, n, h, d_fstart, k, t_idx, t_head, state, prev, out, (unsigned long long *)cnt);
+            dense_round_kernel<CYCLIC><<<dim3((unsigned)rtiles), dim3(DG_THREADS), 0, ctx->stream>>>(
+                cur.idx, cur.head, a, sp.rank, n, h, d_fstart, k, t_idx, t_head, state, prev, out, (unsigned long long *)cnt, tile_big);
             HIPC(hipGetLastError());
         }
         BWTS_TRY(read_small(ctx, SM_DGCNT, DG_CNT_BIG + DG_CNT_SPREAD));
@@ -1812,10 +1828,12 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             u32 *bv[2] = {(u32 *)(bb + 2 * m8), (u32 *)(bb + 2 * m8 + m4)};
             u32 *bpos = (u32 *)(bb + 2 * m8 + 2 * m4);
             {
-                SpanGuard g(ctx, BWTS_K_RERANK, a, 10 * a + 20 * m_big);
-                DgBigIn fin{state, t_head};
-                DgBigOut<CYCLIC> fout{state, t_head, t_idx, a, rb, sp.rank, n, h, d_fstart, k, bk[0], bv[0], bpos};
-                BWTS_TRY((device_scan<false, u64>(ctx, a, fin, fout, OpAdd(), (u64)0, sp.scan_temp)));
+                SpanGuard g(ctx, BWTS_K_RERANK, m_big, 4 * (a / DG_OWN) + 30 * m_big);
+                BWTS_TRY(exclusive_sum_u32(ctx, tile_big, rtiles + 1, sp.scan_temp));
+                dg_big_collect_kernel<<<dim3((unsigned)rtiles), dim3(256), 0, ctx->stream>>>(state, a, tile_big, bpos);
+                DgBigIn fin{bpos, t_head};
+                DgBigOut<CYCLIC> fout{bpos, t_head, t_idx, rb, sp.rank, n, h, d_fstart, k, bk[0], bv[0]};
+                BWTS_TRY((device_scan<false, u32>(ctx, m_big, fin, fout, OpAdd(), 0u, sp.scan_temp)));
             }
             SortPlan bp;
             bp.keys[0] = bk[0]; bp.keys[1] = bk[1];

@@ -20,3 +20,6 @@ k = ctx.timings().as_dict()
 print("inverse %.0f ms wall, device %.0f ms" % (1e3 * dt, k["total_ms"]), {x: round(v["ms"], 1) for x, v in k["kernels"].items()},
       "cycles", k["factors"], "unreached", k["unvisited"], flush=True)
 print("round trip exact:", ctx.device_equal(a, c, n))
+for name, fn, src, dst in (("forward", ctx.forward_device, a, b), ("inverse", ctx.inverse_device, b, c)):
+    t0 = time.perf_counter(); fn(src, n, dst); dt = time.perf_counter() - t0
+    print("%s again (arenas in place): %.0f ms wall = %.2f GB/s" % (name, 1e3 * dt, n / 1e9 / dt), flush=True)
