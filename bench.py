@@ -54,8 +54,24 @@ def cpu_baseline(kind, sample_log2n):
     back = O.inverse(y)
     inv_s = time.perf_counter() - t0
     assert np.array_equal(back, x)
+    # the reference's own suffix sorter (mk_bwts_sa.c:48), timed on the same sample if the box happens to have the library
+    # (this image does not: then the row says so)
+    dss = None
+    try:
+        import ctypes
+        import ctypes.util
+        name = ctypes.util.find_library("divsufsort")
+        if name:
+            L = ctypes.CDLL(name)
+            sa = np.empty(n, dtype=np.int32)
+            t0 = time.perf_counter()
+            rc = L.divsufsort(ctypes.c_void_p(x.ctypes.data), ctypes.c_void_p(sa.ctypes.data), ctypes.c_int32(n))
+            dss = {"divsufsort_s": round(time.perf_counter() - t0, 3), "rc": int(rc)}
+    except Exception as e:          # absent or unusable: reported, not fatal
+        dss = {"error": repr(e)}
     return {
         "value": round(n / 1e6 / fwd_s, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+        "libdivsufsort": dss if dss is not None else "not installed on this box (the reference links it: Makefile:4)",
         "sample": "first 2^%d bytes of the %s(seed=1) stream; oracle/bwts_oracle.c forward (own SA-IS suffix sorter + "
                   "reference fix-up), single thread" % (sample_log2n, kind),
         "forward_s": round(fwd_s, 3),

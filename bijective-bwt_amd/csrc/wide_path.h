@@ -190,7 +190,9 @@ static WideKnobs wide_knobs(void)
 static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
 {
     if (n > (1ull << 36)) return BWTS_E_RANGE;
-    const WideKnobs kn = wide_knobs();
+    WideKnobs kn = wide_knobs();
+    // buckets of 2^31 elements (half as many collection passes over the text) while rank array + bucket buffers + in/out leave room
+    if (!getenv("BWTS_WIDE_BUCKET") && n <= (14ull << 30)) kn.bucket_cap = 1ull << 31;
     const u64 seg = 1ull << kn.seg_log2;
     const u64 nseg = (n + seg - 1) / seg;
     const u64 tiles = scan_tiles(n);
