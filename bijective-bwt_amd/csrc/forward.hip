@@ -1457,7 +1457,7 @@ __global__ __launch_bounds__(DG_THREADS) void dg_minpos_kernel(const u32 *__rest
             for (u32 m = 0; m < ds.sz[j]; m++) { const u32 q = pos[ds.gs[j] + m]; mn = q < mn ? q : mn; }
             sk = mn;
         } else sk = n + (u64)ds.h[j];
-        keys[e] = ((u64)ds.h[j] << kb) | sk;
+        keys[e] = ((u64)ds.h[j] << (kb > 32 ? 32 : kb)) | (kb > 32 ? sk >> (kb - 32) : sk);      // n > 2^31: the order key drops its lowest bit
         vals[e] = ds.idx[j];
     }
 }
@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(256) void dg_unpack_kernel(const u64 *__restrict__ 
                                                         u32 *__restrict__ idx, u32 *__restrict__ head)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> kb); }
+    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> (kb > 32 ? 32 : kb)); }
 }
 
 // Workgroup w looks at list elements [w * DG_OWN - DG_CAP, ... + DG_SPAN): LDS slot sl <-> element e = w * DG_OWN - DG_CAP + sl,
@@ -1749,6 +1749,94 @@ static int build_ranks(bwts_ctx *ctx, const u32 *SA, u64 n, const ActiveList &l,
     return BWTS_OK;
 }
 
+// ---- which round does a group have to take part in? ------------------------------------------------------------------------
+// With the list ordered by position, the copies of a repeated stretch appear as RUNS: consecutive groups G_j, G_j+1, ... whose
+// members are those of the previous group shifted by one position (and no member is a factor's first position).  In a round with
+// step h the successors of G_j's members are then exactly the members of G_j+h -- which, as long as that group has not been
+// worked on, are tied with each other: G_j cannot split.  Only the last h groups of what is left of a run can.  Rounds run with
+// steps h0, 2 h0, 4 h0, ...: the group D groups away from its run's end (D = 1 for the last one) is first able to split in the
+// round r with h0 (2^r - 1) < D <= h0 (2^(r+1) - 1), a function of D alone.  So every group gets its ACTIVATION ROUND once, the
+// list is partitioned by it (stable), and round r works on what earlier rounds left tied plus the groups activated in r -- a
+// position inside a repeat of length R is touched when the step reaches it, not in each of the log R rounds before.
+// (Nothing here is a heuristic: a group that is not yet active provably does not split in that round.)
+#define DG_MAX_ACT 48
+template <bool CYCLIC>
+__global__ __launch_bounds__(DG_THREADS) void dg_runflags_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, u64 a, u64 n,
+                                                                 const u32 *__restrict__ fstart, u64 k, u8 *__restrict__ gflag /* bit 0: a group starts here; bit 1: a run starts here */)
+{
+    __shared__ u32 hd[DG_SPAN];
+    __shared__ u32 pos[DG_SPAN];
+    __shared__ u64 startm[DG_SPAN / 64];
+    const int tid = threadIdx.x;
+    const long long e0 = (long long)blockIdx.x * DG_OWN - DG_CAP;
+    DgSlots ds;
+    dg_detect(idx, head, a, e0, hd, startm, ds);
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const long long e = e0 + j * DG_THREADS + tid;
+        pos[j * DG_THREADS + tid] = (e >= 0 && (u64)e < a) ? idx[e] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const u32 sl = (u32)j * DG_THREADS + tid;
+        const long long e = e0 + sl;
+        if (sl < DG_CAP || sl >= DG_CAP + DG_OWN || e < 0 || (u64)e >= a) continue;
+        const bool gstart = (startm[sl >> 6] >> (sl & 63u)) & 1ull;
+        u32 g = 0;
+        if (gstart) {
+            g = 3;                                               // a run starts here unless the group continues the one before it
+            if (ds.kind[j] == 1 && ds.gs[j] == sl && sl >= ds.sz[j] + 1) {
+                const u32 sz = ds.sz[j], ps = sl - sz;           // the group before this one must be exactly slots [ps, sl)
+                bool cont = (e0 + (long long)ps >= 0) && ((startm[ps >> 6] >> (ps & 63u)) & 1ull);
+                for (u32 m = 1; m < sz && cont; m++) cont = !((startm[(ps + m) >> 6] >> ((ps + m) & 63u)) & 1ull);
+                for (u32 m = 0; m < sz && cont; m++) {
+                    const u32 q = pos[sl + m];
+                    cont = pos[ps + m] + 1u == q && q != 0u;
+                    if (CYCLIC && cont) { const u64 f = factor_of(fstart, k, q); cont = fstart[f] != q; }
+                }
+                if (cont) g = 1;
+            }
+        }
+        gflag[e] = (u8)g;
+    }
+}
+struct DgRunIn {
+    const u8 *gflag;
+    __device__ __forceinline__ u64 operator()(u64 e) const { const u32 g = gflag[e]; return ((u64)((g >> 1) & 1u) << 32) | (u64)(g & 1u); }
+};
+struct DgRunOut {
+    const u8 *gflag; u32 *gord; u32 *rid; u32 *gfirst; u64 a; u64 *totals;
+    __device__ __forceinline__ void operator()(u64 e, u64 v) const            // inclusive: groups and runs started up to here
+    {
+        const u32 go = (u32)v - 1u, ri = (u32)(v >> 32) - 1u;
+        gord[e] = go; rid[e] = ri;
+        if (gflag[e] & 2u) gfirst[ri] = go;
+        if (e + 1 == a) { totals[0] = (u64)(u32)v; totals[1] = v >> 32; }
+    }
+};
+__global__ __launch_bounds__(256) void dg_actkeys_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, const u32 *__restrict__ gord,
+                                                         const u32 *__restrict__ rid, const u32 *__restrict__ gfirst, u64 a, const u64 *__restrict__ totals,
+                                                         u64 h0, u64 *__restrict__ keys, u32 *__restrict__ vals)
+{
+    const u64 e = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a) return;
+    const u64 ngroups = totals[0], nruns = totals[1];
+    const u32 ri = rid[e];
+    const u64 glast = ((u64)ri + 1 < nruns ? (u64)gfirst[ri + 1] : ngroups) - 1;
+    const u64 D = glast - (u64)gord[e] + 1;                      // groups from this one to the end of its run, itself included
+    u32 act = 0;
+    for (u64 lim = h0; D > lim && act < DG_MAX_ACT - 1; lim = 2 * lim + h0) act++;
+    keys[e] = ((u64)head[e] << 8) | act;
+    vals[e] = idx[e];
+}
+__global__ __launch_bounds__(256) void dg_unpack8_kernel(const u64 *__restrict__ keys, const u32 *__restrict__ vals, u64 a,
+                                                         u32 *__restrict__ idx, u32 *__restrict__ head)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < a) { idx[i] = vals[i]; head[i] = (u32)(keys[i] >> 8); }
+}
+
 // The rounds after round 0 when many elements are tied (dense rank array in sp.rank): see dense_round_kernel.
 // cur: the tied list left by round 0 (group-contiguous).  On return the ranks in sp.rank are final (members of a group
 // of equal infinite words share their group's first slot); with need_sa the suffix array is rebuilt from them.
@@ -1761,12 +1849,12 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     const size_t e4 = align_up((size_t)a * 4, 256), e1 = align_up((size_t)a, 256);
     char *base = nullptr;
     const size_t tb4 = align_up(((size_t)a / DG_OWN + 3) * 4, 256);
-    BWTS_TRY(aux_reserve(ctx, 6 * e4 + e1 + tb4, &base));
-    u32 *tile_big = (u32 *)(base + 6 * e4 + e1);
+    BWTS_TRY(aux_reserve(ctx, 8 * e4 + e1 + tb4, &base));
+    u32 *tile_big = (u32 *)(base + 8 * e4 + e1);
     u32 *t_idx = (u32 *)base, *t_head = (u32 *)(base + e4);
     u8 *state = (u8 *)(base + 2 * e4);
-    ActiveList sets[2];
-    for (int i = 0; i < 2; i++) {
+    ActiveList sets[3];        // [0]: the list after round 0 in its final order (the master); [1], [2]: the rounds' working lists
+    for (int i = 0; i < 3; i++) {
         sets[i].idx = (u32 *)(base + 2 * e4 + e1 + (size_t)(2 * i) * e4);
         sets[i].head = (u32 *)(base + 2 * e4 + e1 + (size_t)(2 * i + 1) * e4);
         sets[i].slot = nullptr;
@@ -1776,36 +1864,94 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u8 *out = CYCLIC ? sp.carry_out : nullptr;
     u32 rounds = *rounds_io;
     int nxt = 0;
+    const u64 a0 = a;
+    bool by_rounds = false;                  // the list is partitioned by activation round (master), cur holds what is active
+    ActiveList master{nullptr, nullptr, nullptr};
+    u64 act_start[DG_MAX_ACT + 1];
+    for (int r = 0; r <= DG_MAX_ACT; r++) act_start[r] = 0;
     static const bool reorder_ok = [] { const char *e = getenv("BWTS_DENSE_ORDER"); return !(e && atoi(e) == 0); }();
     const int kb = bitlen_u64(2 * n - 1);
-    if (reorder_ok && kb <= 32 && a >= (1ull << 16)) {
+    if (reorder_ok && a >= (1ull << 16)) {
         // groups in the order of their smallest position (see dg_minpos_kernel); the sorted list lands in sets[0]
         char *ob = nullptr;
         const size_t a8 = align_up((size_t)a * 8, 256);
-        BWTS_TRY(aux_reserve_slot(ctx, 1, 2 * a8 + 2 * e4, &ob));
-        SortPlan op;
-        op.keys[0] = (u64 *)ob; op.keys[1] = (u64 *)(ob + a8);
-        op.vals[0] = (u32 *)(ob + 2 * a8); op.vals[1] = (u32 *)(ob + 2 * a8 + e4);
-        op.tile_hist = sp.tile_hist; op.scan_temp = sp.scan_temp;
-        {
-            SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
-            dg_minpos_kernel<<<dim3((unsigned)((a + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a, n, kb, op.keys[0], op.vals[0]);
-            HIPC(hipGetLastError());
+        const int orc = aux_reserve_slot(ctx, 1, 2 * a8 + 2 * e4, &ob);
+        if (orc != BWTS_OK && orc != BWTS_E_NOMEM) return orc;
+        if (orc == BWTS_OK) {      // (no room for the sort buffers, e.g. text at n = 2^32: the rounds run on the list as it is)
+            SortPlan op;
+            op.keys[0] = (u64 *)ob; op.keys[1] = (u64 *)(ob + a8);
+            op.vals[0] = (u32 *)(ob + 2 * a8); op.vals[1] = (u32 *)(ob + 2 * a8 + e4);
+            op.tile_hist = sp.tile_hist; op.scan_temp = sp.scan_temp;
+            {
+                SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
+                dg_minpos_kernel<<<dim3((unsigned)((a + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a, n, kb, op.keys[0], op.vals[0]);
+                HIPC(hipGetLastError());
+            }
+            // (ordering by fewer bits was measured: 16 bits cost 30 ms more in the rounds than the two saved passes, 24 bits 25 ms more
+            // than the one saved pass -- consecutive groups have to touch consecutive ranks, not just nearby ones)
+            int ores = 0;
+            BWTS_TRY(radix_sort_pairs(ctx, op, a, kb > 32 ? 32 : kb, &ores));
+            {
+                SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
+                dg_unpack_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(op.keys[ores], op.vals[ores], a, kb, sets[0].idx, sets[0].head);
+                HIPC(hipGetLastError());
+            }
+            cur = sets[0];
+            nxt = 1;
+            static const bool runs_ok = [] { const char *e = getenv("BWTS_DENSE_RUNS"); return !(e && atoi(e) == 0); }();
+            if (runs_ok) {
+                // activation rounds (see dg_runflags_kernel): flags -> group / run ordinals -> distance to the run's end -> stable
+                // partition of the list by activation round.  Scratch: the rounds' working buffers, not in use yet.
+                SpanGuard g(ctx, BWTS_K_RERANK, a, 60 * a);
+                u8 *gflag = state;
+                u32 *gord = t_idx, *rid = t_head, *gfirst = sets[1].idx;
+                u64 *totals = cnt + 4;
+                dg_runflags_kernel<CYCLIC><<<dim3((unsigned)((a + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a, n, d_fstart, k, gflag);
+                DgRunIn rin{gflag};
+                DgRunOut rout{gflag, gord, rid, gfirst, a, totals};
+                BWTS_TRY((device_scan<true, u64>(ctx, a, rin, rout, OpAdd(), (u64)0, sp.scan_temp)));
+                dg_actkeys_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(cur.idx, cur.head, gord, rid, gfirst, a, totals, (u64)al.hstep,
+                                                                                                   op.keys[0], op.vals[0]);
+                HIPC(hipGetLastError());
+                int pres = 0;
+                BWTS_TRY(radix_sort_pairs(ctx, op, a, 8, &pres));
+                dg_unpack8_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(op.keys[pres], op.vals[pres], a, sets[0].idx, sets[0].head);
+                HIPC(hipGetLastError());
+                // where each activation round's share starts: row 0 of the pass's scanned tile table (digit-major offsets)
+                u32 hb[256];
+                HIPC(hipMemcpyAsync(hb, sp.tile_hist, sizeof(hb), hipMemcpyDeviceToHost, ctx->stream));
+                HIPC(hipStreamSynchronize(ctx->stream));
+                for (int r = 0; r < DG_MAX_ACT; r++) act_start[r] = hb[r];
+                act_start[DG_MAX_ACT] = a;
+                for (int r = 0; r < DG_MAX_ACT; r++) if (act_start[r] > act_start[r + 1]) return BWTS_E_INTERNAL;
+                by_rounds = true;
+                master = sets[0];
+                cur = sets[1];
+                nxt = 2;
+                a = 0;                       // nothing is active yet: round 0 takes its share below
+            }
         }
-        // (ordering by fewer bits was measured: 16 bits cost 30 ms more in the rounds than the two saved passes, 24 bits 25 ms more
-        // than the one saved pass -- consecutive groups have to touch consecutive ranks, not just nearby ones)
-        int ores = 0;
-        BWTS_TRY(radix_sort_pairs(ctx, op, a, kb, &ores));
-        {
-            SpanGuard g(ctx, BWTS_K_RERANK, a, 20 * a);
-            dg_unpack_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(op.keys[ores], op.vals[ores], a, kb, sets[0].idx, sets[0].head);
-            HIPC(hipGetLastError());
-        }
-        cur = sets[0];
-        nxt = 1;
     }
-    for (u64 h = (u64)al.hstep;; h <<= 1) {
+    u64 act_round = 0;
+    u64 rest_from = a0;                       // master elements from here on were never activated (only when the loop ends on "no split")
+    for (u64 h = (u64)al.hstep;; h <<= 1, act_round++) {
         rounds++;
+        if (by_rounds && act_round < DG_MAX_ACT) {
+            // this round's newly active groups join what earlier rounds left tied
+            const u64 lo = act_start[act_round], cntb = act_start[act_round + 1] - lo;
+            if (cntb) {
+                HIPC(hipMemcpyAsync(cur.idx + a, master.idx + lo, cntb * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+                HIPC(hipMemcpyAsync(cur.head + a, master.head + lo, cntb * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+                a += cntb;
+            }
+        }
+        const u64 waiting = by_rounds && act_round + 1 <= DG_MAX_ACT ? a0 - act_start[act_round + 1 < DG_MAX_ACT ? act_round + 1 : DG_MAX_ACT] : 0;
+        if (a == 0) {
+            if (waiting == 0) break;
+            if (CYCLIC && rounds - 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[rounds - 1] = waiting;
+            if (rounds > 80) return BWTS_E_INTERNAL;
+            continue;                        // no group can split at this step; the next activation round comes with a larger one
+        }
         HIPC(hipMemsetAsync(cnt, 0, (DG_CNT_BIG + DG_CNT_SPREAD) * sizeof(u64), ctx->stream));
         const u64 rtiles = (a + DG_OWN - 1) / DG_OWN;
         HIPC(hipMemsetAsync(tile_big + rtiles, 0, sizeof(u32), ctx->stream));      // the scan below turns counts into offsets; entry [rtiles] = total
@@ -1865,11 +2011,13 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         const u64 splits = ctx->h_small[SM_DGCNT + 2];
         if (a_new > a) return BWTS_E_INTERNAL;
         cur = sets[nxt];
-        nxt ^= 1;
+        nxt = by_rounds ? (nxt == 1 ? 2 : 1) : nxt ^ 1;
         a = a_new;
-        if (CYCLIC && rounds - 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[rounds - 1] = a;
-        if (a == 0) break;
-        if (CYCLIC && splits == 0) break;               // partition stable under doubling: equal infinite words
+        if (CYCLIC && rounds - 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[rounds - 1] = a + waiting;
+        if (a == 0 && waiting == 0) break;
+        // no group split -- the groups still waiting for their activation round provably do not split either -- so the partition is
+        // stable under doubling: what is left are groups of equal infinite words
+        if (CYCLIC && splits == 0) { rest_from = by_rounds ? act_start[act_round + 1 < DG_MAX_ACT ? act_round + 1 : DG_MAX_ACT] : a0; break; }
         if (!CYCLIC && h >= n) return BWTS_E_INTERNAL;  // suffixes are distinct; cannot happen
         if (rounds > 80) return BWTS_E_INTERNAL;
     }
@@ -1885,6 +2033,14 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         DgRestIn rin{cur.head};
         DgRestOut rout{cur.idx, cur.head, prev, out, need_sa ? SA : nullptr};
         BWTS_TRY((device_scan<true, u32>(ctx, a, rin, rout, OpMax(), 0u, sp.scan_temp)));
+    }
+    if (by_rounds && rest_from < a0) {
+        // ... and so do the groups that were still waiting for their activation round
+        const u64 m = a0 - rest_from;
+        SpanGuard g(ctx, BWTS_K_EMIT, m, 10 * m);
+        DgRestIn rin{master.head + rest_from};
+        DgRestOut rout{master.idx + rest_from, master.head + rest_from, prev, out, need_sa ? SA : nullptr};
+        BWTS_TRY((device_scan<true, u32>(ctx, m, rin, rout, OpMax(), 0u, sp.scan_temp)));
     }
     *rounds_io = rounds;
     return BWTS_OK;
