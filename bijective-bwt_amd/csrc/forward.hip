@@ -1898,7 +1898,11 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             }
             cur = sets[0];
             nxt = 1;
-            static const bool runs_ok = [] { const char *e = getenv("BWTS_DENSE_RUNS"); return !(e && atoi(e) == 0); }();
+            // Opt-in (BWTS_DENSE_RUNS=1).  Exact, but measured slower on every text at hand (synthetic 282 -> 319 ms, real text
+            // +7 %): groups' compositions change every few positions when three or more copies overlap, so runs are short, most
+            // groups are activated within four rounds and then wait in the always-active rest like before -- while the flags,
+            // ordinals and the partition cost 35 ms.  It pays on inputs that are two copies of one text.
+            static const bool runs_ok = [] { const char *e = getenv("BWTS_DENSE_RUNS"); return e && atoi(e) == 1; }();
             if (runs_ok) {
                 // activation rounds (see dg_runflags_kernel): flags -> group / run ordinals -> distance to the run's end -> stable
                 // partition of the list by activation round.  Scratch: the rounds' working buffers, not in use yet.

@@ -684,7 +684,7 @@ def test_text_1GiB_properties(ctx):
     {"BWTS_RX_PACK": "0"},                            # round-0 sort on wide (u64, u32, u8) streams instead of packed ones
     {"BWTS_GROUPSCAN": "keys"},                       # round-0 group scan element-wise over the keys instead of flag words
     {"BWTS_RANKBUILD": "plain"},
-    {"BWTS_DENSE_RUNS": "0"},                         # group-local rounds over the whole tied list every round (no activation rounds)
+    {"BWTS_DENSE_RUNS": "1"},                         # activation rounds from the run structure of the position-ordered list (opt-in)
     {"BWTS_DENSE_ORDER": "0"},                        # ... and without ordering the list by position
     {"BWTS_DENSE": "legacy"},                         # later rounds with many ties: list in SA order, radix-sorted, instead of the group-local rounds
     {"BWTS_DENSE": "legacy", "BWTS_SEGSORT": "0"},                            # later rounds: radix sort of the whole tied list instead of sorting small groups in place
