@@ -17,6 +17,7 @@
 #include "scan_templ.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>

@@ -239,12 +239,16 @@ struct WiLenIn {
 };
 struct WiEndOut {
     const WiCycle *cyc; const u32 *order; u64 m; u64 last; u64 *end_by_leader; u64 *end_of_cyc; u64 *total;
+    u64 *end_by_unit_leader;      // cycles ranked as unit nodes (leader tagged WI_UNIT_TAG), or null
     __device__ __forceinline__ void operator()(u64 j, u64 used) const
     {
         const u32 i = order[j];
         const WiCycle c = cyc[i];
         const u64 end = last - used;
-        if (c.leader != WI_NIL) end_by_leader[c.leader] = end;
+        if (c.leader != WI_NIL) {
+            if (c.leader & 0x80000000u) end_by_unit_leader[c.leader & 0x7fffffffu] = end;
+            else end_by_leader[c.leader] = end;
+        }
         end_of_cyc[i] = end;
         if (j + 1 == m) *total = used + c.len;
     }
@@ -305,6 +309,50 @@ __global__ __launch_bounds__(256) void tiny_place_wide_kernel(const WiCycle *__r
         x = y;
     }
 }
+
+// ---- cycles without a splitter that are too long for one lane --------------------------------------------------------------
+// (structured inputs: no regular splitter i * 2^WI_G_LOG2 on a cycle of tens of thousands of elements).  Every unreached
+// element becomes a node of its own -- length 1, successor = the compact index of LF[x] -- and the node kernels above rank that
+// list in parallel (O(nu log nu) work, about 110 bytes per unreached element, taken from the device for the call).
+#define WI_UNIT_TAG 0x80000000u      // leader indices of these cycles are kept apart from the splitter nodes'
+__global__ __launch_bounds__(256) void wi_unit_index_kernel(const u64 *__restrict__ uidx, u64 nu, u64 *__restrict__ LF)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < nu) LF[uidx[i]] = i;                     // the entry's old value lives on in ulf[i]
+}
+__global__ __launch_bounds__(256) void wi_unit_nodes_kernel(const u64 *__restrict__ uidx, const u64 *__restrict__ ulf, u64 nu, const u64 *__restrict__ LF,
+                                                            WiNode *__restrict__ nodes)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < nu) { WiNode nd; nd.nxt = (u32)LF[ulf[i]]; nd.len = 1; nd.mn = uidx[i]; nd.off = 0; nd.pad = 0; nodes[i] = nd; }
+}
+__global__ __launch_bounds__(256) void wi_unit_tag_kernel(WiCycle *__restrict__ cyc, u64 m)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) cyc[i].leader |= WI_UNIT_TAG;
+}
+// wi_place_kernel + place_segments_wide_kernel for nodes of one symbol
+__global__ __launch_bounds__(256) void wi_unit_place_kernel(u64 nu, const WiMin *__restrict__ rec, const WiSum *__restrict__ sh, const u64 *__restrict__ dist,
+                                                            const u64 *__restrict__ min_dist, const u64 *__restrict__ end_by_leader,
+                                                            const u64 *__restrict__ ulf, const u64 *__restrict__ Cg, u8 *__restrict__ out)
+{
+    __shared__ u64 Ctab[257];
+    for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
+    __syncthreads();
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= nu) return;
+    const u32 l = rec[v].leader;
+    const u64 L = sh[l].sum, dm = min_dist[l], d = dist[v];
+    const u64 t = d >= dm ? d - dm : d + L - dm;
+    out[end_by_leader[l] - t] = (u8)symbol_of64(Ctab, ulf[v]);
+}
+// device memory for one call (the rare paths): released when the call returns
+struct ScopedDeviceBlock {
+    bwts_ctx *ctx; char *p = nullptr;
+    explicit ScopedDeviceBlock(bwts_ctx *c) : ctx(c) {}
+    int take(size_t bytes) { if (hipMalloc((void **)&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return BWTS_E_NOMEM; } return BWTS_OK; }
+    ~ScopedDeviceBlock() { if (p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(p); } }
+};
 
 static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
@@ -444,9 +492,41 @@ static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
         HIPC(hipGetLastError());
     }
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
-    const u64 kt = ctx->h_small[SMI_COUNTERS + 7];
-    if (ctx->h_small[SMI_COUNTERS + 4]) return BWTS_E_RANGE;          // a cycle without a splitter too long for one lane
+    u64 kt = ctx->h_small[SMI_COUNTERS + 7];
     if (kt > nu) return BWTS_E_INTERNAL;
+    // a cycle without a splitter too long for one lane: all unreached elements are ranked as nodes of one symbol instead
+    const bool unit_rank = ctx->h_small[SMI_COUNTERS + 4] != 0;
+    ScopedDeviceBlock ub(ctx);
+    WiMin *umin[2] = {nullptr, nullptr};
+    WiSum *usum[2] = {nullptr, nullptr};
+    u64 *udist = nullptr, *umind = nullptr, *uend = nullptr;
+    int ucur = 0, usc = 0;
+    if (unit_rank) {
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, nu, 0);
+        if (nu >= 0x7ffffff0ull) return BWTS_E_NOMEM;
+        const size_t a24 = align_up(nu * sizeof(WiNode), 256), a16 = align_up(nu * 16, 256), a8 = align_up(nu * 8, 256);
+        BWTS_TRY(ub.take(a24 + 4 * a16 + 3 * a8));
+        WiNode *unodes = (WiNode *)ub.p;
+        umin[0] = (WiMin *)(ub.p + a24); umin[1] = (WiMin *)(ub.p + a24 + a16);
+        usum[0] = (WiSum *)(ub.p + a24 + 2 * a16); usum[1] = (WiSum *)(ub.p + a24 + 3 * a16);
+        udist = (u64 *)(ub.p + a24 + 4 * a16); umind = udist + a8 / 8; uend = umind + a8 / 8;
+        const int gb = grid1(nu);
+        const int R2 = [&] { int b = 0; for (u64 x = nu; x; x >>= 1) b++; return b; }();
+        HIPC(hipMemsetAsync(ticket + 9, 0, sizeof(u64), ctx->stream));
+        wi_unit_index_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(uidx, nu, LF);
+        wi_unit_nodes_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(uidx, ulf, nu, LF, unodes);
+        wi_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, unodes, umin[0]);
+        for (int r = 0; r < R2; r++, ucur ^= 1) wi_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, umin[ucur], umin[ucur ^ 1]);
+        wi_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, unodes, umin[ucur], usum[0]);
+        for (int r = 0; r < R2; r++, usc ^= 1) wi_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, usum[usc], usum[usc ^ 1]);
+        wi_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, umin[ucur], usum[usc], unodes, udist, umind, cyc, ticket + 9);
+        HIPC(hipGetLastError());
+        BWTS_TRY(read_small(ctx, SMI_COUNTERS + 9, 1));
+        kt = ctx->h_small[SMI_COUNTERS + 9];          // these cycles take the place of the one-lane scan's
+        if (kt == 0 || kt > nu) return BWTS_E_INTERNAL;
+        wi_unit_tag_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(cyc, kt);
+        HIPC(hipGetLastError());
+    }
     const u64 kall = kc + kt;
     ctx->tm.factors = kall;
     {
@@ -465,7 +545,7 @@ static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
         for (u64 x = n - 1; x; x >>= 1) kbits++;
         BWTS_TRY(radix_sort_pairs(ctx, cp, kall, kbits < 1 ? 1 : kbits, &res));
         WiLenIn lin{cyc, cp.vals[res]};
-        WiEndOut lout{cyc, cp.vals[res], kall, n - 1, end_by_leader, end_of_cyc, ctx->d_small + SMI_COUNTERS + 13};
+        WiEndOut lout{cyc, cp.vals[res], kall, n - 1, end_by_leader, end_of_cyc, ctx->d_small + SMI_COUNTERS + 13, uend};
         BWTS_TRY((device_scan<false, u64>(ctx, kall, lin, lout, OpAdd(), (u64)0, cp.scan_temp)));
         wi_place_kernel<<<dim3(grid1(s_all)), dim3(256), 0, ctx->stream>>>(s_all, wmin[cur], wsum[sc], dist, min_dist, end_by_leader, opos, wrap_at, cyc_len);
         HIPC(hipGetLastError());
@@ -476,7 +556,9 @@ static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
         const u64 threads = s_all << tpn_log2;
         place_segments_wide_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(seg, s_all, slot, tpn_log2, nodes, opos, wrap_at, cyc_len,
                                                                                                            d_out);
-        if (kt) tiny_place_wide_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(cyc, kt, end_of_cyc, LF, dC, d_out);
+        if (unit_rank)
+            wi_unit_place_kernel<<<dim3(grid1(nu)), dim3(256), 0, ctx->stream>>>(nu, umin[ucur], usum[usc], udist, umind, uend, ulf, dC, d_out);
+        else if (kt) tiny_place_wide_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(cyc, kt, end_of_cyc, LF, dC, d_out);
         HIPC(hipGetLastError());
     }
     BWTS_TRY(read_small(ctx, SMI_COUNTERS + 13, 1));

@@ -522,6 +522,29 @@ for kat in (b"banana", b"mississippi", b"abracadabra", b"the quick brown fox jum
     os.environ["BWTS_WIDE_BUCKET"] = "256"
     with pkg.Context(0) as ctx:
         assert ctx.forward(kat).tobytes() == O.forward(kat).tobytes(), kat
+# one context for a run of inputs (arenas and registers carry over), among them sorted runs: thousands of one-symbol Lyndon
+# factors, i.e. thousands of single-lane waves in the key patch kernel (the case behind tools/check_shift64.py)
+os.environ["BWTS_WIDE_BUCKET"] = "4096"
+rng = np.random.default_rng(9038)
+with pkg.Context(0) as ctx:
+    for rep in range(6):
+        big = O.generate("zipf", 150000 + rep, 40 + rep)
+        assert np.array_equal(ctx.forward(big), O.forward(big)), ("shared context, zipf", rep)
+        n = int(rng.integers(5000, 12000))
+        x = np.sort(rng.integers(0, 100, size=n, dtype=np.uint8))[::-1].copy()
+        c = int(rng.integers(0, n))
+        x = (np.concatenate([x[c:], x[:c]]) + 48).astype(np.uint8)
+        y = ctx.forward(x)
+        assert np.array_equal(y, O.forward(x)), ("shared context, sorted run", rep, n)
+        assert np.array_equal(ctx.inverse(y), x)
+# inverse of data whose LF map has a long cycle that meets no regular splitter: B = 1^b 0^c sends i to i + c (mod n); with
+# n = 2^k and c = 2 * odd that is two cycles of n / 2 elements, the odd one free of multiples of 256 (unit-node ranking)
+with pkg.Context(0) as ctx:
+    for n, c in ((1 << 17, 50002), (1 << 20, 2 * 177771)):
+        B = np.concatenate([np.full(n - c, 1, np.uint8), np.zeros(c, np.uint8)])
+        assert np.array_equal(ctx.inverse(B), O.inverse(B)), ("long cycle without a splitter", n)
+        x = O.generate("zipf", 100000, n)
+        assert np.array_equal(ctx.inverse(x), O.inverse(x))
 print("wide ok")
 """ % (ROOT, os.path.join(ROOT, "tests"), WIDE_CASES)
     env = dict(os.environ, BWTS_TEST_CHILD="1", BWTS_FORCE_WIDE="2", BWTS_WIDE_SEG_LOG2="13")
