@@ -1,6 +1,6 @@
 """Build-time check of the device code: 64-bit shifts whose shift amount sits in the wave's last allocated VGPR.
 
-Found in round 2 on MI355X (tools/README.md, DESIGN.md section 10): v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64 read a wrong shift
+Found in round 2 on MI355X (tools/README.md, DESIGN.md section 9): v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64 read a wrong shift
 amount when the amount register is the last VGPR of the wave's allocation (register number = 7 mod 8 and nothing allocated
 behind it) and other waves share the SIMD.  LLVM knows this as the gfx90a "shift64 high register" erratum and moves the
 amount to another register there; for gfx950 it does not.  This script compiles every .hip file of the library to device
