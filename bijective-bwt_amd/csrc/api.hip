@@ -180,6 +180,7 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
     HIPC(hipSetDevice(ctx->device));
     spans_reset(ctx);
     ctx->tm.n = n;
+    ctx->call_block_bytes = 0;
     HIPC(hipEventRecord(ctx->ev_begin, ctx->stream));
     int rc = fn(ctx, (const u8 *)d_in, n, (u8 *)d_out);
     if (rc != BWTS_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
@@ -188,7 +189,7 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
     float ms = 0.f;
     HIPC(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     ctx->tm.total_ms = ms;
-    ctx->tm.device_bytes = ctx->arena_cap + ctx->aux_cap[0] + ctx->aux_cap[1] + ctx->d_io_cap[0] + ctx->d_io_cap[1];
+    ctx->tm.device_bytes = ctx->arena_cap + ctx->aux_cap[0] + ctx->aux_cap[1] + ctx->d_io_cap[0] + ctx->d_io_cap[1] + ctx->call_block_bytes;
     return BWTS_OK;
 }
 

@@ -51,6 +51,7 @@ struct CopyPool {
 struct bwts_ctx {
     int device;
     hipStream_t stream;
+    size_t call_block_bytes = 0;        // device memory taken for one call only (rare paths), largest of the last call
     int last_hip;
 
     // device arena: one allocation, bump-allocated per call, grown between calls

@@ -753,8 +753,34 @@ size_t inverse_arena_bytes(u64 n)
 
 static int grid1(u64 m) { return (int)((m + 255) / 256); }
 
-// One attempt with splitter spacing 2^g.  *retry is set when the node pool overflows or a cycle without a splitter is
-// longer than one lane may follow (adversarial LF); the caller then repeats with g = 0 (every element a splitter).
+#include "wide_inverse.h"         // the 64-bit form; its node-ranking kernels also serve the unit-node ranking below
+
+// wi_finish_kernel for the main path: the cycles of the unit-node ranking go straight into the record form of the cycles
+// without a splitter (smallest element, length) plus their leader
+__global__ __launch_bounds__(256) void unit_finish_kernel(u64 s, const WiMin *__restrict__ rec, const WiSum *__restrict__ sh, const WiNode *__restrict__ nodes,
+                                                          u64 *__restrict__ dist, u64 *__restrict__ min_dist, uint2 *__restrict__ tiny, u32 *__restrict__ leader,
+                                                          unsigned long long *__restrict__ ncyc)
+{
+    const u64 v = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (v >= s) return;
+    const WiMin r = rec[v];
+    const u64 L = sh[r.leader].sum, d = L - sh[v].sum;
+    dist[v] = d;
+    if (nodes[v].mn == r.mn) min_dist[r.leader] = d + nodes[v].off;
+    if (r.leader == (u32)v) {
+        const unsigned long long at = atomicAdd(ncyc, 1ull);
+        tiny[at] = make_uint2((u32)r.mn, (u32)L);
+        leader[at] = r.leader;
+    }
+}
+__global__ __launch_bounds__(256) void unit_ends_kernel(const u32 *__restrict__ leader, const u32 *__restrict__ end_of_tiny, u64 m, u32 *__restrict__ end_by_leader)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) end_by_leader[leader[i]] = end_of_tiny[i];
+}
+
+// One attempt with splitter spacing 2^g.  *retry is set when the node pool overflows (adversarial LF) or the unreached
+// elements are too many for the unit-node ranking; the caller then repeats with g = 0 (every element a splitter).
 static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int g, int mark, bool *retry, bool *ambiguous)
 {
     *retry = false;
@@ -948,9 +974,43 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     }
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
     const u64 kc = ctx->h_small[SMI_COUNTERS + 2];
-    const u64 kt = ctx->h_small[SMI_COUNTERS + 7];
-    if (ctx->h_small[SMI_COUNTERS + 4]) { *retry = true; return BWTS_OK; }   // a cycle without a splitter too long for one lane
+    u64 kt = ctx->h_small[SMI_COUNTERS + 7];
     if (kc == 0 || kc > s2all || kt > nu) return BWTS_E_INTERNAL;
+    // A cycle without a splitter too long for one lane (sorted or periodic data: 1^b 0^c with n = 2^k, c = 2 * odd has a cycle of
+    // n / 2 odd elements): every unreached element becomes a node of one symbol and the pointer-jumping kernels of the 64-bit
+    // form rank that list -- memory and work by the number of unreached elements, not by n (wide_inverse.h).
+    const bool unit_rank = ctx->h_small[SMI_COUNTERS + 4] != 0;
+    ScopedDeviceBlock ub(ctx);
+    WiMin *umin[2] = {nullptr, nullptr};
+    WiSum *usum[2] = {nullptr, nullptr};
+    u64 *udist = nullptr, *umind = nullptr;
+    u32 *uend = nullptr, *uleader = nullptr;
+    int ucur = 0, usc = 0;
+    if (unit_rank) {
+        if (nu >= 0x7ffffff0ull) { *retry = true; return BWTS_OK; }
+        SpanGuard sg(ctx, BWTS_K_LISTRANK, nu, 0);
+        const size_t a24 = align_up(nu * sizeof(WiNode), 256), a16 = align_up(nu * 16, 256), a8 = align_up(nu * 8, 256), a4 = align_up(nu * 4, 256);
+        if (ub.take(a24 + 4 * a16 + 2 * a8 + 2 * a4) != BWTS_OK) { *retry = true; return BWTS_OK; }      // 112 bytes per unreached element
+        WiNode *unodes = (WiNode *)ub.p;
+        umin[0] = (WiMin *)(ub.p + a24); umin[1] = (WiMin *)(ub.p + a24 + a16);
+        usum[0] = (WiSum *)(ub.p + a24 + 2 * a16); usum[1] = (WiSum *)(ub.p + a24 + 3 * a16);
+        udist = (u64 *)(ub.p + a24 + 4 * a16); umind = (u64 *)(ub.p + a24 + 4 * a16 + a8);
+        uend = (u32 *)(ub.p + a24 + 4 * a16 + 2 * a8); uleader = (u32 *)(ub.p + a24 + 4 * a16 + 2 * a8 + a4);
+        const int gb = grid1(nu);
+        const int R2 = [&] { int b = 0; for (u64 x = nu; x; x >>= 1) b++; return b; }();
+        HIPC(hipMemsetAsync(ticket + 9, 0, sizeof(u64), ctx->stream));
+        wi_unit_index_kernel<u32><<<dim3(gb), dim3(256), 0, ctx->stream>>>(uidx, nu, LF);        // LF[x] of an unreached x lives on in ulf
+        wi_unit_nodes_kernel<u32><<<dim3(gb), dim3(256), 0, ctx->stream>>>(uidx, ulf, nu, LF, unodes);
+        wi_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, unodes, umin[0]);
+        for (int r = 0; r < R2; r++, ucur ^= 1) wi_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, umin[ucur], umin[ucur ^ 1]);
+        wi_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, unodes, umin[ucur], usum[0]);
+        for (int r = 0; r < R2; r++, usc ^= 1) wi_jump_sum_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, usum[usc], usum[usc ^ 1]);
+        unit_finish_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, umin[ucur], usum[usc], unodes, udist, umind, tiny, uleader, ticket + 9);
+        HIPC(hipGetLastError());
+        BWTS_TRY(read_small(ctx, SMI_COUNTERS + 9, 1));
+        kt = ctx->h_small[SMI_COUNTERS + 9];              // these cycles take the place of the one-lane scan's
+        if (kt == 0 || kt > nu) return BWTS_E_INTERNAL;
+    }
     const u64 kall = kc + kt;
     ctx->tm.factors = kall;
 
@@ -973,6 +1033,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         CycleLenIn lin{cl, cp.vals[res]};
         CycleEndOut lout{cl, cp.vals[res], (u32)(n - 1), end_by_leader, end_of_tiny, ctx->d_small + SMI_COUNTERS + 13};
         BWTS_TRY((device_scan<false, u32>(ctx, kall, lin, lout, OpAdd(), 0u, cp.scan_temp)));
+        if (unit_rank) unit_ends_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(uleader, end_of_tiny, kt, uend);
         lr_place2_kernel<<<dim3(grid1(s2all)), dim3(256), 0, ctx->stream>>>(s2all, lrmin[cur], lrsum[sc], dist, min_dist, end_by_leader, place2);
         lr2_distribute_kernel<<<dim3(grid1(s2all)), dim3(256), 0, ctx->stream>>>(noderec, s2, s2all, U, place2, d_opos, d_wrap, d_clen);
         HIPC(hipGetLastError());
@@ -987,7 +1048,9 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         const u64 threads = s_all << tpn_log2;
         place_segments_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(seg, s_all, slot, tpn_log2, noderec,
                                                                                                       d_opos, d_wrap, d_clen, d_out);
-        if (kt) tiny_place_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(tiny, kt, end_of_tiny, LF, dC, d_out);
+        if (unit_rank)
+            wi_unit_place_kernel<u32><<<dim3(grid1(nu)), dim3(256), 0, ctx->stream>>>(nu, umin[ucur], usum[usc], udist, umind, uend, ulf, dC, d_out);
+        else if (kt) tiny_place_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(tiny, kt, end_of_tiny, LF, dC, d_out);
         HIPC(hipGetLastError());
     }
     BWTS_TRY(read_small(ctx, SMI_COUNTERS + 13, 1));
@@ -998,8 +1061,6 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     }
     return BWTS_OK;
 }
-
-#include "wide_inverse.h"
 
 int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {

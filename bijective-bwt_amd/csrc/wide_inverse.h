@@ -315,12 +315,14 @@ __global__ __launch_bounds__(256) void tiny_place_wide_kernel(const WiCycle *__r
 // element becomes a node of its own -- length 1, successor = the compact index of LF[x] -- and the node kernels above rank that
 // list in parallel (O(nu log nu) work, about 110 bytes per unreached element, taken from the device for the call).
 #define WI_UNIT_TAG 0x80000000u      // leader indices of these cycles are kept apart from the splitter nodes'
-__global__ __launch_bounds__(256) void wi_unit_index_kernel(const u64 *__restrict__ uidx, u64 nu, u64 *__restrict__ LF)
+template <typename IDX>      // u64 here, u32 on the main path (inverse.hip)
+__global__ __launch_bounds__(256) void wi_unit_index_kernel(const IDX *__restrict__ uidx, u64 nu, IDX *__restrict__ LF)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < nu) LF[uidx[i]] = i;                     // the entry's old value lives on in ulf[i]
+    if (i < nu) LF[uidx[i]] = (IDX)i;                // the entry's old value lives on in ulf[i]
 }
-__global__ __launch_bounds__(256) void wi_unit_nodes_kernel(const u64 *__restrict__ uidx, const u64 *__restrict__ ulf, u64 nu, const u64 *__restrict__ LF,
+template <typename IDX>
+__global__ __launch_bounds__(256) void wi_unit_nodes_kernel(const IDX *__restrict__ uidx, const IDX *__restrict__ ulf, u64 nu, const IDX *__restrict__ LF,
                                                             WiNode *__restrict__ nodes)
 {
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -332,9 +334,10 @@ __global__ __launch_bounds__(256) void wi_unit_tag_kernel(WiCycle *__restrict__ 
     if (i < m) cyc[i].leader |= WI_UNIT_TAG;
 }
 // wi_place_kernel + place_segments_wide_kernel for nodes of one symbol
+template <typename IDX>
 __global__ __launch_bounds__(256) void wi_unit_place_kernel(u64 nu, const WiMin *__restrict__ rec, const WiSum *__restrict__ sh, const u64 *__restrict__ dist,
-                                                            const u64 *__restrict__ min_dist, const u64 *__restrict__ end_by_leader,
-                                                            const u64 *__restrict__ ulf, const u64 *__restrict__ Cg, u8 *__restrict__ out)
+                                                            const u64 *__restrict__ min_dist, const IDX *__restrict__ end_by_leader,
+                                                            const IDX *__restrict__ ulf, const u64 *__restrict__ Cg, u8 *__restrict__ out)
 {
     __shared__ u64 Ctab[257];
     for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
@@ -344,13 +347,18 @@ __global__ __launch_bounds__(256) void wi_unit_place_kernel(u64 nu, const WiMin 
     const u32 l = rec[v].leader;
     const u64 L = sh[l].sum, dm = min_dist[l], d = dist[v];
     const u64 t = d >= dm ? d - dm : d + L - dm;
-    out[end_by_leader[l] - t] = (u8)symbol_of64(Ctab, ulf[v]);
+    out[(u64)end_by_leader[l] - t] = (u8)symbol_of64(Ctab, (u64)ulf[v]);
 }
 // device memory for one call (the rare paths): released when the call returns
 struct ScopedDeviceBlock {
     bwts_ctx *ctx; char *p = nullptr;
     explicit ScopedDeviceBlock(bwts_ctx *c) : ctx(c) {}
-    int take(size_t bytes) { if (hipMalloc((void **)&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return BWTS_E_NOMEM; } return BWTS_OK; }
+    int take(size_t bytes)
+    {
+        if (hipMalloc((void **)&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return BWTS_E_NOMEM; }
+        if (bytes > ctx->call_block_bytes) ctx->call_block_bytes = bytes;
+        return BWTS_OK;
+    }
     ~ScopedDeviceBlock() { if (p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(p); } }
 };
 
@@ -513,8 +521,8 @@ static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
         const int gb = grid1(nu);
         const int R2 = [&] { int b = 0; for (u64 x = nu; x; x >>= 1) b++; return b; }();
         HIPC(hipMemsetAsync(ticket + 9, 0, sizeof(u64), ctx->stream));
-        wi_unit_index_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(uidx, nu, LF);
-        wi_unit_nodes_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(uidx, ulf, nu, LF, unodes);
+        wi_unit_index_kernel<u64><<<dim3(gb), dim3(256), 0, ctx->stream>>>(uidx, nu, LF);
+        wi_unit_nodes_kernel<u64><<<dim3(gb), dim3(256), 0, ctx->stream>>>(uidx, ulf, nu, LF, unodes);
         wi_init_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, unodes, umin[0]);
         for (int r = 0; r < R2; r++, ucur ^= 1) wi_jump_min_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, umin[ucur], umin[ucur ^ 1]);
         wi_cut_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(nu, unodes, umin[ucur], usum[0]);
@@ -557,7 +565,7 @@ static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
         place_segments_wide_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(seg, s_all, slot, tpn_log2, nodes, opos, wrap_at, cyc_len,
                                                                                                            d_out);
         if (unit_rank)
-            wi_unit_place_kernel<<<dim3(grid1(nu)), dim3(256), 0, ctx->stream>>>(nu, umin[ucur], usum[usc], udist, umind, uend, ulf, dC, d_out);
+            wi_unit_place_kernel<u64><<<dim3(grid1(nu)), dim3(256), 0, ctx->stream>>>(nu, umin[ucur], usum[usc], udist, umind, uend, ulf, dC, d_out);
         else if (kt) tiny_place_wide_kernel<<<dim3(grid1(kt)), dim3(256), 0, ctx->stream>>>(cyc, kt, end_of_cyc, LF, dC, d_out);
         HIPC(hipGetLastError());
     }

@@ -244,6 +244,26 @@ def test_inverse_low_entropy_large(pkg):
         assert np.array_equal(ctx.forward(got), x)
 
 
+def test_inverse_long_cycle_without_splitter(pkg):
+    """B = 1^b 0^c sends i to i + c (mod n); with n = 2^k and c = 2 * odd that is two cycles of n / 2 elements, and the odd one
+    meets none of the regular splitters.  Such elements are ranked as nodes of one symbol (memory by their number); the
+    earlier answer -- every element a splitter -- needed 129 n bytes."""
+    with pkg.Context(0) as ctx:
+        for n, c in ((1 << 17, 50002), (1 << 24, 2 * 2777771)):
+            B = np.concatenate([np.full(n - c, 1, np.uint8), np.zeros(c, np.uint8)])
+            got = ctx.inverse(B)
+            t = ctx.timings()
+            assert np.array_equal(got, O.inverse(B)), n
+            assert t.factors == 2 and t.unvisited == n // 2
+        n, c = 1 << 26, 2 * 12345679
+        B = np.concatenate([np.full(n - c, 1, np.uint8), np.zeros(c, np.uint8)])
+        got = ctx.inverse(B)
+        print("device bytes / n at 2^26: %.1f" % (ctx.timings().device_bytes / n))
+        assert ctx.timings().device_bytes < 110 * n      # 56 n for the unit nodes (half the elements are unreached) + LF, marks, log, lists
+        assert np.array_equal(ctx.forward(got), B)          # bijection: the forward transform of the text is B again
+        assert np.array_equal(np.bincount(got, minlength=2), np.bincount(B, minlength=2))
+
+
 @pytest.mark.parametrize("off_in,off_out", [(1, 0), (3, 5), (0, 7), (13, 2)])
 def test_unaligned_device_pointers(ctx, off_in, off_out):
     """Device entry points take any byte address (the vectorised kernels fall back when a pointer is not 16-byte aligned)."""
