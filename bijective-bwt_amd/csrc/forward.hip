@@ -1356,10 +1356,15 @@ __global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restric
 //   be refined, which orders at least as finely as the unrefined one and never differently (ranks only ever split).
 // Larger groups (a few per cent of the elements after the first rounds) are flagged, compacted, ordered by the radix
 // sort, regrouped with a scan and put back.  A stable compaction of the surviving elements gives the next round's list.
-#define DG_CAP     16
+#ifndef DG_CAP
+#define DG_CAP     128         // measured 16 .. 256 (text with repeats): 128 with 4 slots per thread is the best of them
+#endif
 #define DG_THREADS 512
-#define DG_ITEMS   2
+#ifndef DG_ITEMS
+#define DG_ITEMS   4
+#endif
 #define DG_SPAN    (DG_THREADS * DG_ITEMS)            // list elements a workgroup looks at
+#define DG_WORDS_BACK ((DG_CAP + 63) / 64)           // 64-slot words either side of a slot's own in which its group's ends may lie
 #define DG_OWN     (DG_SPAN - 2 * DG_CAP - 1)         // ... and decides: DG_CAP in front and DG_CAP + 1 behind are only looked at
 #define DG_FS_LDS  1024                  // factor starts kept in LDS when there are at most this many
 #define DG_CNT_BIG    8                 // counters[DG_CNT_BIG .. + DG_CNT_SPREAD): elements of larger groups, spread over many addresses
@@ -1411,17 +1416,25 @@ __device__ __forceinline__ void dg_detect(const u32 *__restrict__ idx, const u32
         const u32 sl = (u32)j * DG_THREADS + tid;
         ds.kind[j] = 0; ds.idx[j] = 0; ds.gs[j] = 0; ds.sz[j] = 0;
         if (!valid[j]) continue;
-        // last start at or before sl, first start after sl: bit scans over at most two 64-slot words each
+        // last start at or before sl, first start after sl: bit scans over the slot's 64-slot word and DG_WORDS_BACK words either side
         const u32 w = sl >> 6, b = sl & 63u;
         const u64 cur = startm[w];
         const u64 below = b == 63 ? cur : cur & ((2ull << b) - 1ull);
         int gs = -1;
         if (below) gs = (int)(w * 64 + 63 - (u32)__clzll((long long)below));
-        else if (w > 0) { const u64 pm = startm[w - 1]; if (pm) gs = (int)((w - 1) * 64 + 63 - (u32)__clzll((long long)pm)); }
+        else {
+#pragma unroll
+            for (u32 d = 1; d <= DG_WORDS_BACK; d++)
+                if (gs < 0 && w >= d) { const u64 pm = startm[w - d]; if (pm) gs = (int)((w - d) * 64 + 63 - (u32)__clzll((long long)pm)); }
+        }
         const u64 above = b == 63 ? 0ull : cur >> (b + 1);
         int ge = -1;
         if (above) ge = (int)(sl + 1 + (u32)__ffsll((unsigned long long)above) - 1);
-        else if (w + 1 < DG_SPAN / 64) { const u64 nm = startm[w + 1]; if (nm) ge = (int)((w + 1) * 64 + (u32)__ffsll((unsigned long long)nm) - 1); }
+        else {
+#pragma unroll
+            for (u32 d = 1; d <= DG_WORDS_BACK; d++)
+                if (ge < 0 && w + d < DG_SPAN / 64) { const u64 nm = startm[w + d]; if (nm) ge = (int)((w + d) * 64 + (u32)__ffsll((unsigned long long)nm) - 1); }
+        }
         const bool small = gs >= 1 && ge >= 0 && ge - gs <= DG_CAP;
         if (small) {
             if (gs >= DG_CAP && gs < DG_CAP + DG_OWN) { ds.kind[j] = 1; ds.gs[j] = (u32)gs; ds.sz[j] = (u32)(ge - gs); }
@@ -1576,10 +1589,11 @@ __global__ __launch_bounds__(256) void dg_big_collect_kernel(const u8 *__restric
     const u32 lo = tile_off[blockIdx.x], cnt = tile_off[blockIdx.x + 1] - lo;
     if (cnt == 0) return;
     const u64 e0 = (u64)blockIdx.x * DG_OWN;
-    u32 f[4], mine = 0;
+    constexpr int PER = (DG_OWN + 255) / 256;                         // blocked: PER consecutive elements per thread
+    u32 f[PER], mine = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {                                     // blocked: 4 consecutive elements per thread (4 * 256 >= DG_OWN)
-        const u32 r = threadIdx.x * 4 + j;
+    for (int j = 0; j < PER; j++) {
+        const u32 r = threadIdx.x * PER + j;
         const u64 e = e0 + r;
         f[j] = (r < DG_OWN && e < a && (state[e] & 3) == DG_BIG) ? 1u : 0u;
         mine += f[j];
@@ -1587,7 +1601,7 @@ __global__ __launch_bounds__(256) void dg_big_collect_kernel(const u8 *__restric
     u32 total;
     u32 at = lo + block_scan_exclusive<u32, OpAdd, 4>(mine, OpAdd(), 0u, scan_sm, &total);
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (f[j]) bigidx[at++] = (u32)(e0 + threadIdx.x * 4 + j);
+    for (int j = 0; j < PER; j++) if (f[j]) bigidx[at++] = (u32)(e0 + threadIdx.x * PER + j);
 }
 struct DgBigIn {
     const u32 *bigidx; const u32 *head;
