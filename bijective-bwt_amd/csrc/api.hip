@@ -137,6 +137,7 @@ extern "C" int bwts_ctx_create(bwts_ctx **out, int device_id)
     void *p = nullptr;
     if (hipMalloc(&p, 4096 * sizeof(u64)) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_NOMEM; }
     ctx->d_small = (u64 *)p;
+    if (hipMemset(p, 0, 4096 * sizeof(u64)) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_HIP; }     // (counters that kernels expect at zero)
     if (hipHostMalloc(&p, 4096 * sizeof(u64), hipHostMallocDefault) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_NOMEM; }
     ctx->h_small = (u64 *)p;
     if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_HIP; }

@@ -48,6 +48,8 @@ struct CopyPool {
 
 #define STAGE_SLOTS 4
 
+#define SM_RX_SYNC 4090          // d_small word holding the two 32-bit counters of radix_column_scan_fused_kernel (zero between launches)
+
 struct bwts_ctx {
     int device;
     hipStream_t stream;

@@ -741,10 +741,66 @@ static int launch_scatter(bwts_ctx *ctx, int cfg, u64 tiles, const u64 *kin, con
 
 // [tile][digit] counts -> global exclusive offsets in digit-major order, in place.
 // tile_hist must be followed by the chunk table (radix_tile_hist_bytes()).
+// The three steps above in one launch, for tables of at most RX_FUSED_CHUNKS chunks (sorts of up to 2^28 elements): one workgroup
+// per chunk, thread = digit.  Every workgroup publishes its chunk's column sums, waits until all have (at most 256 workgroups of
+// 256 threads: always resident together, and the only wait in the kernel), then adds up what lies before its chunk -- the chunks
+// before it in its own column, all of the smaller digits' columns -- and rewrites its chunk.  sync[0] counts arrivals, sync[1]
+// departures; the last workgroup to leave puts both back to zero for the next launch.
+// (The sort of a few million pairs spent as long in the five launches it replaces as in the histogram sweep itself.)
+#define RX_FUSED_CHUNKS 256
+__global__ __launch_bounds__(256) void radix_column_scan_fused_kernel(u32 *__restrict__ tile_hist, u64 tiles, u32 chunks, u32 *__restrict__ chunk_sum,
+                                                                      unsigned int *__restrict__ sync)
+{
+    __shared__ u32 scan_sm[4];
+    const u32 c = blockIdx.x, d = threadIdx.x;
+    const u64 t0 = (u64)c * RX_CHUNK;
+    const u64 t1 = t0 + RX_CHUNK < tiles ? t0 + RX_CHUNK : tiles;
+    u32 s = 0;
+    for (u64 t = t0; t < t1; t++) s += tile_hist[t * 256 + d];
+    __hip_atomic_store(&chunk_sum[(u64)c * 256 + d], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    if (d == 0) {
+        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunks) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    __threadfence();
+    u32 before = 0, total = 0;
+    for (u32 cc = 0; cc < chunks; cc++) {
+        const u32 v = __hip_atomic_load(&chunk_sum[(u64)cc * 256 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        total += v;
+        before += cc < c ? v : 0u;
+    }
+    u32 all;
+    const u32 base = block_scan_exclusive<u32, OpAdd, 4>(total, OpAdd(), 0u, scan_sm, &all);      // elements with a smaller digit
+    u32 run = base + before;
+    for (u64 t = t0; t < t1; t++) {
+        const u32 v = tile_hist[t * 256 + d];
+        tile_hist[t * 256 + d] = run;
+        run += v;
+    }
+    __syncthreads();
+    if (d == 0) {
+        const u32 left = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (left + 1 == chunks) {          // everyone has read the sums and passed the wait
+            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp)
 {
     const u64 chunks = radix_chunks(tiles);
     u32 *chunk_sum = (u32 *)((char *)tile_hist + align_up((size_t)tiles * 256 * sizeof(u32), 256));
+    static const bool fused_ok = [] { const char *e = getenv("BWTS_RX_FUSED_SCAN"); return !(e && atoi(e) == 0); }();
+    if (fused_ok && chunks <= RX_FUSED_CHUNKS) {
+        radix_column_scan_fused_kernel<<<dim3((unsigned)chunks), dim3(256), 0, ctx->stream>>>(tile_hist, tiles, (u32)chunks, chunk_sum,
+                                                                                             (unsigned int *)(ctx->d_small + SM_RX_SYNC));
+        HIPC(hipGetLastError());
+        return BWTS_OK;
+    }
     radix_chunk_sum_kernel<<<dim3((unsigned)chunks), dim3(256), 0, ctx->stream>>>(tile_hist, tiles, chunks, chunk_sum);
     BWTS_TRY(exclusive_sum_u32(ctx, chunk_sum, chunks * 256, scan_temp));
     radix_chunk_apply_kernel<<<dim3((unsigned)chunks), dim3(256), 0, ctx->stream>>>(tile_hist, tiles, chunks, chunk_sum);
