@@ -1490,7 +1490,9 @@ __global__ __launch_bounds__(256) void dg_unpack_kernel(const u64 *__restrict__ 
 // counters: [2] a group split, [DG_CNT_BIG ...] elements of larger groups.  rank[] is only read here: the new ranks are applied by the
 // compaction pass at the end of the round (dg_compact_kernel) -- a round's keys must all come from the same version of the
 // ranks: a member that already shows its new rank next to a group-mate that still shows the old one would order the wrong way.
-template <bool CYCLIC>
+// NKEYS = 3: the step is quadrupled -- members are ordered by the ranks of their successors at h, 2h and 3h, all read from the
+// same h-consistent rank array, so one round does the work of two doublings (half the rounds, half the list passes).
+template <bool CYCLIC, int NKEYS>
 __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, u64 a,
                                                                  const u32 *__restrict__ rank, u64 n, u64 h,
                                                                  const u32 *__restrict__ fstart, u64 k,
@@ -1500,6 +1502,7 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
 {
     __shared__ u32 hd[DG_SPAN];              // group heads
     __shared__ u32 key[DG_SPAN];             // successor ranks of the members of the groups this workgroup orders
+    __shared__ u64 key23[NKEYS == 3 ? DG_SPAN : 1];      // ... and the ranks two and three steps on
     __shared__ u64 startm[DG_SPAN / 64];     // bit = a group starts at this slot (an element outside the list counts as a start)
     __shared__ u32 fs[DG_FS_LDS];
     __shared__ u32 cnt_big, any_split;
@@ -1513,9 +1516,11 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
     u32 (&my_idx)[DG_ITEMS] = ds.idx, (&my_gs)[DG_ITEMS] = ds.gs, (&my_sz)[DG_ITEMS] = ds.sz, (&my_kind)[DG_ITEMS] = ds.kind, (&myh)[DG_ITEMS] = ds.h;
     // successor ranks of the members ordered here
     u32 my_key[DG_ITEMS];
+    u64 my_key23[NKEYS == 3 ? DG_ITEMS : 1];
 #pragma unroll
     for (int j = 0; j < DG_ITEMS; j++) {
         my_key[j] = 0;
+        if (NKEYS == 3) my_key23[NKEYS == 3 ? j : 0] = 0;
         if (my_kind[j] != 1) continue;
         const u64 p = my_idx[j];
         if (CYCLIC) {
@@ -1525,14 +1530,26 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
             const u64 s0 = fs_lds ? fs[lo] : fstart[lo];
             const u64 e1 = lo + 1 < k ? (u64)(fs_lds ? fs[lo + 1] : fstart[lo + 1]) : n;
             my_key[j] = rank[cyclic_successor(p, s0, e1 - s0, h)];
+            if (NKEYS == 3) {
+                const u32 r2 = rank[cyclic_successor(p, s0, e1 - s0, 2 * h)], r3 = rank[cyclic_successor(p, s0, e1 - s0, 3 * h)];
+                my_key23[NKEYS == 3 ? j : 0] = ((u64)r2 << 32) | r3;
+            }
         } else {
             const u64 q = p + h;
             my_key[j] = q < n ? rank[q] + 1u : 0u;
+            if (NKEYS == 3) {
+                const u64 q2 = p + 2 * h, q3 = p + 3 * h;
+                const u32 r2 = q2 < n ? rank[q2] + 1u : 0u, r3 = q3 < n ? rank[q3] + 1u : 0u;
+                my_key23[NKEYS == 3 ? j : 0] = ((u64)r2 << 32) | r3;
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < DG_ITEMS; j++)
-        if (my_kind[j] == 1) key[j * DG_THREADS + tid] = my_key[j];
+        if (my_kind[j] == 1) {
+            key[j * DG_THREADS + tid] = my_key[j];
+            if (NKEYS == 3) key23[NKEYS == 3 ? j * DG_THREADS + tid : 0] = my_key23[NKEYS == 3 ? j : 0];
+        }
     __syncthreads();
     // order inside the group by counting; results first, then the loads of the emission, then every store
     u32 dst_off[DG_ITEMS], newhead[DG_ITEMS], st_out[DG_ITEMS];
@@ -1546,11 +1563,23 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
         if (my_kind[j] != 1) continue;
         const u32 gs = my_gs[j], sz = my_sz[j], mine = my_key[j];
         u32 less = 0, eq = 0, eq_before = 0;
-        for (u32 m = 0; m < sz; m++) {
-            const u32 ko = key[gs + m];
-            less += ko < mine ? 1u : 0u;
-            eq += ko == mine ? 1u : 0u;
-            eq_before += (ko == mine && gs + m < sl) ? 1u : 0u;
+        if (NKEYS == 3) {
+            const u64 mine23 = my_key23[NKEYS == 3 ? j : 0];
+            for (u32 m = 0; m < sz; m++) {
+                const u32 ko = key[gs + m];
+                const u64 ko23 = key23[NKEYS == 3 ? gs + m : 0];
+                const bool same = ko == mine && ko23 == mine23;
+                less += (ko < mine || (ko == mine && ko23 < mine23)) ? 1u : 0u;
+                eq += same ? 1u : 0u;
+                eq_before += (same && gs + m < sl) ? 1u : 0u;
+            }
+        } else {
+            for (u32 m = 0; m < sz; m++) {
+                const u32 ko = key[gs + m];
+                less += ko < mine ? 1u : 0u;
+                eq += ko == mine ? 1u : 0u;
+                eq_before += (ko == mine && gs + m < sl) ? 1u : 0u;
+            }
         }
         dst_off[j] = gs + less + eq_before;
         newhead[j] = myh[j] + less;
@@ -1611,25 +1640,41 @@ template <bool CYCLIC>
 struct DgBigOut {
     const u32 *bigidx; const u32 *head; const u32 *idx; int rb; const u32 *rank; u64 n; u64 h; const u32 *fstart; u64 k;
     u64 *bk; u32 *bv;
+    u64 *k23;        // quadrupled step: (rank two steps on) << rb | (rank three steps on), kept for the regrouping ...
+    u64 *k23_sort;   // ... and a copy that the first of the two sorts consumes, with the elements' indices beside it
+    u32 *j_sort;
     __device__ __forceinline__ void operator()(u64 j, u32 before) const
     {
         const u32 i = bigidx[j];
         const u32 st = (j == 0 || head[i] != head[bigidx[j - 1]]) ? 1u : 0u;
         const u64 ord = (u64)before + st - 1;
         const u64 p = idx[i];
-        u64 r2;
+        u64 r1, r2 = 0, r3 = 0;
         if (CYCLIC) {
             const u64 f = factor_of(fstart, k, p);
             const u64 s0 = fstart[f], L = factor_end(fstart, k, n, f) - s0;
-            r2 = rank[cyclic_successor(p, s0, L, h)];
+            r1 = rank[cyclic_successor(p, s0, L, h)];
+            if (k23) { r2 = rank[cyclic_successor(p, s0, L, 2 * h)]; r3 = rank[cyclic_successor(p, s0, L, 3 * h)]; }
         } else {
             const u64 q = p + h;
-            r2 = q < n ? (u64)rank[q] + 1ull : 0ull;
+            r1 = q < n ? (u64)rank[q] + 1ull : 0ull;
+            if (k23) {
+                const u64 q2 = p + 2 * h, q3 = p + 3 * h;
+                r2 = q2 < n ? (u64)rank[q2] + 1ull : 0ull;
+                r3 = q3 < n ? (u64)rank[q3] + 1ull : 0ull;
+            }
         }
-        bk[j] = (ord << rb) | r2;
+        bk[j] = (ord << rb) | r1;
         bv[j] = (u32)p;
+        if (k23) { const u64 v = (r2 << rb) | r3; k23[j] = v; k23_sort[j] = v; j_sort[j] = (u32)j; }
     }
 };
+// between the two sorts of the quadrupled step: the elements, ordered by their second key, take their first key along
+__global__ __launch_bounds__(256) void dg_stage2_keys_kernel(const u32 *__restrict__ jsorted, const u64 *__restrict__ bk, u64 m, u64 *__restrict__ keys2)
+{
+    const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) keys2[i] = bk[jsorted[i]];
+}
 // regrouping of the sorted larger groups.  Scan value (max on both halves): high word = 1 + index of the element's group
 // start, low word = 1 + index of its subgroup start, both in the sorted compacted order.
 struct OpMax2 {
@@ -1639,29 +1684,31 @@ struct OpMax2 {
         return ((u64)(xh > yh ? xh : yh) << 32) | (u64)(xl > yl ? xl : yl);
     }
 };
+// (quadrupled step: bk = the sorted first keys, src[j] = the element that landed in slot j, k23 = second keys by element, pos = positions by
+// element; single step: src and k23 are null and bv holds the positions in sorted order)
 struct DgRegroupIn {
-    const u64 *bk; u64 m; int rb;
+    const u64 *bk; u64 m; int rb; const u32 *src; const u64 *k23;
+    __device__ __forceinline__ bool same(u64 a, u64 b) const { return bk[a] == bk[b] && (!k23 || k23[src[a]] == k23[src[b]]); }
     __device__ __forceinline__ u64 operator()(u64 j) const
     {
-        const u64 kj = bk[j];
-        const bool gstart = j == 0 || (bk[j - 1] >> rb) != (kj >> rb);
-        const bool sstart = gstart || bk[j - 1] != kj;
+        const bool gstart = j == 0 || (bk[j - 1] >> rb) != (bk[j] >> rb);
+        const bool sstart = gstart || !same(j - 1, j);
         return ((u64)(gstart ? (u32)j + 1u : 0u) << 32) | (u64)(sstart ? (u32)j + 1u : 0u);
     }
 };
 struct DgRegroupOut {
     const u64 *bk; const u32 *bv; const u32 *bpos; u64 m; int rb;
     u32 *oidx; u32 *ohead; u8 *state; PrevSym prev; u8 *out; unsigned long long *counters;
+    const u32 *src; const u64 *k23;
     __device__ __forceinline__ void operator()(u64 j, u64 v) const       // inclusive scan value
     {
         const u32 gidx = (u32)(v >> 32) - 1u, sidx = (u32)v - 1u;
-        const u64 kj = bk[j];
-        const bool last_of_sub = j + 1 == m || bk[j + 1] != kj;
+        const bool last_of_sub = j + 1 == m || bk[j + 1] != bk[j] || (k23 && k23[src[j + 1]] != k23[src[j]]);
         const bool alone = sidx == (u32)j && last_of_sub;
         // the j-th flagged list slot: sorting keeps every group on its own slots, and all of them still hold the group's old head
         const u32 at = bpos[j];
         const u32 newhead = ohead[at] + (sidx - gidx);
-        const u32 p = bv[j];
+        const u32 p = src ? bv[src[j]] : bv[j];
         oidx[at] = p; ohead[at] = newhead; state[at] = (u8)((alone ? DG_DONE : DG_KEEP) | (sidx != gidx ? DG_MOVED : 0));
         if (alone && out) out[newhead] = prev(p);
         const u64 splitm = __ballot(sidx != gidx);
@@ -1953,7 +2000,11 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     }
     u64 act_round = 0;
     u64 rest_from = a0;                       // master elements from here on were never activated (only when the loop ends on "no split")
-    for (u64 h = (u64)al.hstep;; h <<= 1, act_round++) {
+    // the step is quadrupled per round (three successor ranks per element) unless BWTS_DENSE_STEP=2 asks for plain doubling;
+    // the activation rounds above are laid out for doubling
+    static const bool step4_ok = [] { const char *e = getenv("BWTS_DENSE_STEP"); return !(e && atoi(e) == 2); }();
+    const int nk = step4_ok && !by_rounds ? 3 : 1;
+    for (u64 h = (u64)al.hstep;; h <<= (nk == 3 ? 2 : 1), act_round++) {
         rounds++;
         if (by_rounds && act_round < DG_MAX_ACT) {
             // this round's newly active groups join what earlier rounds left tied
@@ -1976,8 +2027,12 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         HIPC(hipMemsetAsync(tile_big + rtiles, 0, sizeof(u32), ctx->stream));      // the scan below turns counts into offsets; entry [rtiles] = total
         {
             SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 29 * a);       // idx, head in; idx, head, state out; one rank gather
-            dense_round_kernel<CYCLIC><<<dim3((unsigned)rtiles), dim3(DG_THREADS), 0, ctx->stream>>>(
-                cur.idx, cur.head, a, sp.rank, n, h, d_fstart, k, t_idx, t_head, state, prev, out, (unsigned long long *)cnt, tile_big);
+            if (nk == 3)
+                dense_round_kernel<CYCLIC, 3><<<dim3((unsigned)rtiles), dim3(DG_THREADS), 0, ctx->stream>>>(
+                    cur.idx, cur.head, a, sp.rank, n, h, d_fstart, k, t_idx, t_head, state, prev, out, (unsigned long long *)cnt, tile_big);
+            else
+                dense_round_kernel<CYCLIC, 1><<<dim3((unsigned)rtiles), dim3(DG_THREADS), 0, ctx->stream>>>(
+                    cur.idx, cur.head, a, sp.rank, n, h, d_fstart, k, t_idx, t_head, state, prev, out, (unsigned long long *)cnt, tile_big);
             HIPC(hipGetLastError());
         }
         BWTS_TRY(read_small(ctx, SM_DGCNT, DG_CNT_BIG + DG_CNT_SPREAD));
@@ -1988,30 +2043,56 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             // larger groups: compact (with the successor ranks), radix sort by (group ordinal, successor rank), regroup, put back
             char *bb = nullptr;
             const size_t m8 = align_up((size_t)m_big * 8, 256), m4 = align_up((size_t)m_big * 4, 256);
-            BWTS_TRY(aux_reserve_slot(ctx, 1, 2 * m8 + 3 * m4, &bb));
+            BWTS_TRY(aux_reserve_slot(ctx, 1, (nk == 3 ? 4 : 2) * m8 + (nk == 3 ? 4 : 3) * m4, &bb));
+            // [first keys | second buffer] [positions | second buffer] [list slots]; quadrupled step: + [second keys] [sort buffer] [index buffer]
             u64 *bk[2] = {(u64 *)bb, (u64 *)(bb + m8)};
             u32 *bv[2] = {(u32 *)(bb + 2 * m8), (u32 *)(bb + 2 * m8 + m4)};
             u32 *bpos = (u32 *)(bb + 2 * m8 + 2 * m4);
+            u64 *k23 = nk == 3 ? (u64 *)(bb + 2 * m8 + 3 * m4) : nullptr, *sk1 = nk == 3 ? (u64 *)(bb + 3 * m8 + 3 * m4) : nullptr;
+            u32 *sv1 = nk == 3 ? (u32 *)(bb + 4 * m8 + 3 * m4) : nullptr;
             {
                 SpanGuard g(ctx, BWTS_K_RERANK, m_big, 4 * (a / DG_OWN) + 30 * m_big);
                 BWTS_TRY(exclusive_sum_u32(ctx, tile_big, rtiles + 1, sp.scan_temp));
                 dg_big_collect_kernel<<<dim3((unsigned)rtiles), dim3(256), 0, ctx->stream>>>(state, a, tile_big, bpos);
                 DgBigIn fin{bpos, t_head};
-                DgBigOut<CYCLIC> fout{bpos, t_head, t_idx, rb, sp.rank, n, h, d_fstart, k, bk[0], bv[0]};
+                // quadrupled step: the first sort works on (second key copy in bk[1], element index in bv[1])
+                DgBigOut<CYCLIC> fout{bpos, t_head, t_idx, rb, sp.rank, n, h, d_fstart, k, bk[0], bv[0], k23, bk[1], bv[1]};
                 BWTS_TRY((device_scan<false, u32>(ctx, m_big, fin, fout, OpAdd(), 0u, sp.scan_temp)));
             }
-            SortPlan bp;
-            bp.keys[0] = bk[0]; bp.keys[1] = bk[1];
-            bp.vals[0] = bv[0]; bp.vals[1] = bv[1];
-            bp.tile_hist = sp.tile_hist; bp.scan_temp = sp.scan_temp;
-            int rbig = 0;
             int big_bits = bitlen_u64(m_big / (DG_CAP + 1)) + rb;          // ordinals < m_big / (DG_CAP + 1)
             if (big_bits > 64) return BWTS_E_RANGE;
-            BWTS_TRY(radix_sort_pairs(ctx, bp, m_big, big_bits, &rbig));
+            SortPlan bp;
+            bp.tile_hist = sp.tile_hist; bp.scan_temp = sp.scan_temp;
+            int rbig = 0;
+            const u64 *sorted_k1 = nullptr;
+            const u32 *src = nullptr, *positions = nullptr;
+            if (nk == 3) {
+                // LSD over two key words: stable sort by (rank at 2h, rank at 3h), then by (group ordinal, rank at h)
+                bp.keys[0] = bk[1]; bp.keys[1] = sk1;
+                bp.vals[0] = bv[1]; bp.vals[1] = sv1;
+                int r1 = 0;
+                BWTS_TRY(radix_sort_pairs(ctx, bp, m_big, 2 * rb, &r1));
+                u64 *kin = bp.keys[r1], *kout = bp.keys[r1 ^ 1];
+                u32 *vin = bp.vals[r1], *vout = bp.vals[r1 ^ 1];
+                {
+                    SpanGuard g(ctx, BWTS_K_RERANK, m_big, 20 * m_big);
+                    dg_stage2_keys_kernel<<<dim3((unsigned)((m_big + 255) / 256)), dim3(256), 0, ctx->stream>>>(vin, bk[0], m_big, kin);
+                    HIPC(hipGetLastError());
+                }
+                bp.keys[0] = kin; bp.keys[1] = kout;
+                bp.vals[0] = vin; bp.vals[1] = vout;
+                BWTS_TRY(radix_sort_pairs(ctx, bp, m_big, big_bits, &rbig));
+                sorted_k1 = bp.keys[rbig]; src = bp.vals[rbig]; positions = bv[0];
+            } else {
+                bp.keys[0] = bk[0]; bp.keys[1] = bk[1];
+                bp.vals[0] = bv[0]; bp.vals[1] = bv[1];
+                BWTS_TRY(radix_sort_pairs(ctx, bp, m_big, big_bits, &rbig));
+                sorted_k1 = bk[rbig]; positions = bv[rbig];
+            }
             {
                 SpanGuard g(ctx, BWTS_K_RERANK, m_big, 36 * m_big);
-                DgRegroupIn rin{bk[rbig], m_big, rb};
-                DgRegroupOut rout{bk[rbig], bv[rbig], bpos, m_big, rb, t_idx, t_head, state, prev, out, (unsigned long long *)cnt};
+                DgRegroupIn rin{sorted_k1, m_big, rb, src, k23};
+                DgRegroupOut rout{sorted_k1, positions, bpos, m_big, rb, t_idx, t_head, state, prev, out, (unsigned long long *)cnt, src, k23};
                 BWTS_TRY((device_scan<true, u64>(ctx, m_big, rin, rout, OpMax2(), (u64)0, sp.scan_temp)));
             }
         }

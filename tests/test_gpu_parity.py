@@ -192,7 +192,7 @@ def test_deep_repeats_vs_oracle(ctx):
     block = rng.integers(97, 101, size=50000, dtype=np.uint8)
     x = np.concatenate([block, block[:40000], rng.integers(97, 101, size=1000, dtype=np.uint8), block[10000:], block])
     y = ctx.forward(x)
-    assert ctx.timings().rounds >= 10
+    assert ctx.timings().rounds >= 6              # (repeats of 50 000 symbols; the step is doubled or quadrupled per round)
     assert np.array_equal(y, O.forward(x))
     assert np.array_equal(ctx.inverse(y), x)
 
@@ -203,7 +203,7 @@ def test_dense_ties_large_vs_oracle(ctx):
     x = np.concatenate([block, block, O.generate("zipf", 1000, 6), block[: 1 << 20], block])      # ~7.3 MiB, long repeats
     y = ctx.forward(x)
     t = ctx.timings()
-    assert t.active_after_round0 > len(x) // 32 and t.rounds >= 10
+    assert t.active_after_round0 > len(x) // 32 and t.rounds >= 6
     assert np.array_equal(y, O.forward(x))
     assert np.array_equal(ctx.inverse(y), x)
 
@@ -701,12 +701,12 @@ def test_text_generator_matches_oracle(ctx):
 
 
 def test_text_16MiB_vs_oracle(ctx):
-    """16 MiB of the text workload: most positions tied after round 0, a dozen doubling rounds."""
+    """16 MiB of the text workload: most positions tied after round 0, many rounds on the tied list."""
     n = 1 << 24
     x = O.generate("text", n, 1)
     y = ctx.forward(x)
     t = ctx.timings()
-    assert t.active_after_round0 > n // 4 and t.rounds >= 8
+    assert t.active_after_round0 > n // 4 and t.rounds >= 5
     assert hashlib.sha256(y.tobytes()).hexdigest() == hashlib.sha256(O.forward(x).tobytes()).hexdigest()
     assert np.array_equal(ctx.inverse(y), x)
 
@@ -728,6 +728,7 @@ def test_text_1GiB_properties(ctx):
     {"BWTS_GROUPSCAN": "keys"},                       # round-0 group scan element-wise over the keys instead of flag words
     {"BWTS_RANKBUILD": "plain"},
     {"BWTS_DENSE_RUNS": "1"},                         # activation rounds from the run structure of the position-ordered list (opt-in)
+    {"BWTS_DENSE_STEP": "2"},                         # group-local rounds with plain doubling (one successor rank) instead of the quadrupled step
     {"BWTS_DENSE_ORDER": "0"},                        # ... and without ordering the list by position
     {"BWTS_DENSE": "legacy"},                         # later rounds with many ties: list in SA order, radix-sorted, instead of the group-local rounds
     {"BWTS_DENSE": "legacy", "BWTS_SEGSORT": "0"},                            # later rounds: radix sort of the whole tied list instead of sorting small groups in place
