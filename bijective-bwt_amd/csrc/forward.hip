@@ -1357,7 +1357,7 @@ __global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restric
 // Larger groups (a few per cent of the elements after the first rounds) are flagged, compacted, ordered by the radix
 // sort, regrouped with a scan and put back.  A stable compaction of the surviving elements gives the next round's list.
 #ifndef DG_CAP
-#define DG_CAP     128         // measured 16 .. 256 (text with repeats): 128 with 4 slots per thread is the best of them
+#define DG_CAP     256         // measured 16 .. 512 (text with repeats): with the quadrupled step 256 .. 384 at 4 slots per thread are the best
 #endif
 #define DG_THREADS 512
 #ifndef DG_ITEMS
@@ -2039,6 +2039,8 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         u64 m_big = 0;
         for (int c = 0; c < DG_CNT_SPREAD; c++) m_big += ctx->h_small[SM_DGCNT + DG_CNT_BIG + c];
         if (m_big > a) return BWTS_E_INTERNAL;
+        static const bool round_trace = [] { const char *e = getenv("BWTS_ROUND_TRACE"); return e && atoi(e) == 1; }();
+        if (round_trace) fprintf(stderr, "[rounds] round %u h %llu: list %llu, in larger groups %llu\n", rounds, (unsigned long long)h, (unsigned long long)a, (unsigned long long)m_big);
         if (m_big) {
             // larger groups: compact (with the successor ranks), radix sort by (group ordinal, successor rank), regroup, put back
             char *bb = nullptr;
