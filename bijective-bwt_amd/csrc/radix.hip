@@ -755,37 +755,62 @@ __global__ __launch_bounds__(256) void radix_column_scan_fused_kernel(u32 *__res
     const u32 c = blockIdx.x, d = threadIdx.x;
     const u64 t0 = (u64)c * RX_CHUNK;
     const u64 t1 = t0 + RX_CHUNK < tiles ? t0 + RX_CHUNK : tiles;
+    // (both sweeps over the chunk's tiles keep eight loads in flight: with one at a time a chunk of 128 tiles took 16 us)
     u32 s = 0;
-    for (u64 t = t0; t < t1; t++) s += tile_hist[t * 256 + d];
-    __hip_atomic_store(&chunk_sum[(u64)c * 256 + d], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    __syncthreads();
-    if (d == 0) {
-        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunks) __builtin_amdgcn_s_sleep(2);
+    {
+        u64 t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            u32 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = tile_hist[(t + j) * 256 + d];
+#pragma unroll
+            for (int j = 0; j < 8; j++) s += v[j];
+        }
+        for (; t < t1; t++) s += tile_hist[t * 256 + d];
     }
-    __syncthreads();
-    __threadfence();
-    u32 before = 0, total = 0;
-    for (u32 cc = 0; cc < chunks; cc++) {
-        const u32 v = __hip_atomic_load(&chunk_sum[(u64)cc * 256 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        total += v;
-        before += cc < c ? v : 0u;
+    u32 before = 0, total = s;
+    if (chunks > 1) {            // (one chunk -- up to 2^20 elements: nobody to wait for)
+        chunk_sum[(u64)c * 256 + d] = s;
+        __threadfence();                         // every thread's sums are out before the workgroup reports in
+        __syncthreads();
+        if (d == 0) {
+            __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunks) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        __threadfence();                         // acquire for the whole workgroup: the plain loads below see the other workgroups' sums
+        total = 0;
+        u32 cc = 0;
+        for (; cc + 4 <= chunks; cc += 4) {      // independent loads, four in flight
+            const u32 v0 = chunk_sum[(u64)cc * 256 + d], v1 = chunk_sum[(u64)(cc + 1) * 256 + d];
+            const u32 v2 = chunk_sum[(u64)(cc + 2) * 256 + d], v3 = chunk_sum[(u64)(cc + 3) * 256 + d];
+            total += v0 + v1 + v2 + v3;
+            before += (cc < c ? v0 : 0u) + (cc + 1 < c ? v1 : 0u) + (cc + 2 < c ? v2 : 0u) + (cc + 3 < c ? v3 : 0u);
+        }
+        for (; cc < chunks; cc++) { const u32 v = chunk_sum[(u64)cc * 256 + d]; total += v; before += cc < c ? v : 0u; }
     }
     u32 all;
     const u32 base = block_scan_exclusive<u32, OpAdd, 4>(total, OpAdd(), 0u, scan_sm, &all);      // elements with a smaller digit
     u32 run = base + before;
-    for (u64 t = t0; t < t1; t++) {
-        const u32 v = tile_hist[t * 256 + d];
-        tile_hist[t * 256 + d] = run;
-        run += v;
+    {
+        u64 t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            u32 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = tile_hist[(t + j) * 256 + d];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { tile_hist[(t + j) * 256 + d] = run; run += v[j]; }
+        }
+        for (; t < t1; t++) { const u32 v = tile_hist[t * 256 + d]; tile_hist[t * 256 + d] = run; run += v; }
     }
-    __syncthreads();
-    if (d == 0) {
-        const u32 left = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (left + 1 == chunks) {          // everyone has read the sums and passed the wait
-            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (chunks > 1) {
+        __syncthreads();
+        if (d == 0) {
+            const u32 left = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (left + 1 == chunks) {          // everyone has read the sums and passed the wait
+                __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
