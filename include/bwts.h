@@ -33,7 +33,9 @@ extern "C" {
 #define BWTS_E_NODEVICE -2   /* no HIP device / device id out of range */
 #define BWTS_E_NOMEM    -3   /* device or pinned-host allocation failed */
 #define BWTS_E_HIP      -4   /* a HIP runtime call failed; see bwts_last_hip_error() */
-#define BWTS_E_RANGE    -5   /* n beyond what the engine indexes (n > 2^32) */
+#define BWTS_E_RANGE    -5   /* n beyond what the engine indexes: n > 2^36, or one of the documented limits of the blocked 64-bit
+                                forward path for n > 2^32 (one 12-bit key prefix larger than a bucket, inputs
+                                whose Lyndon factors need the suffix-sort route) */
 #define BWTS_E_INTERNAL -6   /* engine invariant violated (bug) */
 #define BWTS_E_SINK     -7   /* the caller's output sink returned nonzero */
 
