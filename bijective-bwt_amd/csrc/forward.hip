@@ -348,7 +348,7 @@ __device__ __forceinline__ u64 factor_end(const u32 *__restrict__ fstart, u64 k,
 //   c   u16  key bits 32..39 | carried byte << 8      (c16)      or  u8: the carried byte alone (keys of <= 32 bits)
 // where the carried byte of position p is T[cprev(p)] (mk_bwts_sa.c:172-188): T[p-1], fixed at factor heads afterwards.
 // The first pass then reads 6 (5) bytes per element like any other pass, and no separate previous-symbol array exists.
-struct KeyStore { u64 *wide; u32 *lo; u8 *c; bool c16; };
+struct KeyStore { u64 *wide; u32 *lo; u8 *c; bool c16; u8 *wprev; /* beside wide keys: the carried bytes, or null */ };
 __device__ __forceinline__ void ks_store(const KeyStore &ks, u64 i, u64 key)        // the key only (patches)
 {
     if (ks.wide) ks.wide[i] = key;
@@ -356,7 +356,7 @@ __device__ __forceinline__ void ks_store(const KeyStore &ks, u64 i, u64 key)    
 }
 __device__ __forceinline__ void ks_store_with_prev(const KeyStore &ks, u64 i, u64 key, u32 prev)   // key + carried byte (keybuild)
 {
-    if (ks.wide) ks.wide[i] = key;
+    if (ks.wide) { ks.wide[i] = key; if (ks.wprev) ks.wprev[i] = (u8)prev; }
     else {
         ks.lo[i] = (u32)key;
         if (ks.c16) ((u16 *)ks.c)[i] = (u16)(((u32)(key >> 32) & 255u) | (prev << 8));
@@ -374,6 +374,7 @@ static KeyStore key_store_of(u64 *keys0, u64 n, bool split, int key_bits)
     ks.lo = (u32 *)keys0;
     ks.c = (u8 *)keys0 + align_up((size_t)n * 4, 256);
     ks.c16 = key_bits > 32;
+    ks.wprev = nullptr;
     return ks;
 }
 // the carried byte of a factor's first position is the factor's last byte
@@ -977,7 +978,8 @@ struct GroupOut {
 // from __ballot); the scan then runs over n/64 words instead of n elements, and tied_from_flags_kernel turns the set
 // bits into the tied list.  Same outputs as GroupIn/GroupOut with rb < 0, a third of the time.
 #define GF_WORDS 8      // words (of 64 slots) a wave handles per step: eight key loads in flight per lane
-__global__ __launch_bounds__(256) void group_flags_kernel(const u64 *__restrict__ K, u64 n, u64 *__restrict__ headw, u64 *__restrict__ keepw)
+__global__ __launch_bounds__(256) void group_flags_kernel(const u64 *__restrict__ K, u64 n, u64 *__restrict__ headw, u64 *__restrict__ keepw,
+                                                          u64 mask = ~0ull /* key bits that count (the 64-bit path parks position bits above them) */)
 {
     const int lane = lane_id();
     const u64 words = (n + 63) / 64;
@@ -987,12 +989,12 @@ __global__ __launch_bounds__(256) void group_flags_kernel(const u64 *__restrict_
 #pragma unroll
         for (int q = 0; q < GF_WORDS; q++) {
             const u64 i = (w0 + q) * 64 + lane;
-            k[q] = i < n ? K[i] : 0;
+            k[q] = i < n ? K[i] & mask : 0;
         }
         const u64 first = w0 * 64, last = (w0 + GF_WORDS) * 64 - 1;      // the chunk's outer neighbours
         u64 edge = 0;
-        if (lane == 0 && first > 0) edge = K[first - 1];
-        if (lane == 63 && last + 1 < n) edge = K[last + 1];
+        if (lane == 0 && first > 0) edge = K[first - 1] & mask;
+        if (lane == 63 && last + 1 < n) edge = K[last + 1] & mask;
         u64 mine_h = 0, mine_k = 0;
 #pragma unroll
         for (int q = 0; q < GF_WORDS; q++) {
@@ -2464,11 +2466,13 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
 static_assert(KB_TILE == SCAN_TILE, "keybuild0's tile minima feed the scan's final sweep");
 
 // keys of positions [pos0, pos0 + count) into keys0 (index q - pos0), tile minima into tile_min[0 ..)
-static int launch_keybuild0_seg(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, u64 *keys0, u64 *tile_min, bool split, u64 pos0, u64 count)
+static int launch_keybuild0_seg(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, u64 *keys0, u64 *tile_min, bool split, u64 pos0, u64 count,
+                                u8 *wprev = nullptr /* wide keys only: T[q - 1] of every position beside its key */)
 {
     SpanGuard g(ctx, BWTS_K_KEYBUILD, count, count + (split ? 5 : 8) * count);
     const u64 blocks = (count + KB_TILE - 1) / KB_TILE;
-    const KeyStore ks = key_store_of(keys0, count, split, al.key_bits);
+    KeyStore ks = key_store_of(keys0, count, split, al.key_bits);
+    ks.wprev = split ? nullptr : wprev;
     if (al.varlen) {
         keybuild0v_kernel<<<dim3((unsigned)blocks), dim3(KB_THREADS), 0, ctx->stream>>>(d_T, n, ctx->d_small + SM_VTAB, al.key_bits,
                                                                                         ks, tile_min, pos0, pos0 + count);

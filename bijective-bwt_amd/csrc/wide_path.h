@@ -81,18 +81,39 @@ struct WideFilterIn {
     const u64 *keys; int shift; u32 plo, phi;
     __device__ __forceinline__ u32 operator()(u64 i) const { const u32 pf = (u32)(keys[i] >> shift); return pf >= plo && pf < phi ? 1u : 0u; }
 };
+// The byte stream beside (key, position low word) carries the position's bits above 32 -- or, when the key leaves its top
+// four bits free above the bytes the passes sort on (key_bits <= 56: everything but the 64-bit keys of text), those bits ride in the key (no pass sorts on them)
+// and the stream carries the output byte T[cprev(p)], which the key build leaves beside the segment's keys: the finish kernel then has
+// no random read left.
+#define WIDE_HI_SHIFT 60
 struct WideFilterOut {
     const u64 *keys; int shift; u32 plo, phi; u64 pos0; u64 *bk; u32 *bv; u8 *bs;      // bk/bv/bs already point at this segment's share
+    const u8 *segprev;          // the segment's output bytes (key build + wide_head_prev_kernel), or null: the stream carries position bits
     __device__ __forceinline__ void operator()(u64 i, u32 before) const
     {
         const u64 key = keys[i];
         const u32 pf = (u32)(key >> shift);
-        if (pf >= plo && pf < phi) { const u64 p = pos0 + i; bk[before] = key; bv[before] = (u32)p; bs[before] = (u8)(p >> 32); }
+        if (pf >= plo && pf < phi) {
+            const u64 p = pos0 + i;
+            bv[before] = (u32)p;
+            if (segprev) { bk[before] = key | ((p >> 32) << WIDE_HI_SHIFT); bs[before] = segprev[i]; }
+            else { bk[before] = key; bs[before] = (u8)(p >> 32); }
+        }
     }
 };
+// the output byte of a factor's first position is the factor's last byte (mk_bwts_sa.c:172-188); the key build wrote T[p - 1]
+__global__ __launch_bounds__(256) void wide_head_prev_kernel(const u8 *__restrict__ T, u64 n, const u64 *__restrict__ fstart, u64 k, u8 *__restrict__ segprev,
+                                                            u64 pos0, u64 lim)
+{
+    const u64 f = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (f >= k) return;
+    const u64 s = fstart[f];
+    if (s >= pos0 && s < lim) segprev[s - pos0] = T[(f + 1 < k ? fstart[f + 1] : n) - 1];
+}
 
 // a sorted bucket is finished: ranks, output bytes, tied elements
-__global__ __launch_bounds__(256) void wide_bucket_finish_kernel(const u32 *__restrict__ V, const u8 *__restrict__ S, u64 m, u64 base,
+template <bool CARRY>
+__global__ __launch_bounds__(256) void wide_bucket_finish_kernel(const u64 *__restrict__ K, const u32 *__restrict__ V, const u8 *__restrict__ S, u64 m, u64 base,
                                                                  const u64 *__restrict__ headw, const u64 *__restrict__ keepw, const u64 *__restrict__ pre,
                                                                  u64 *__restrict__ rank64, PrevSym64 prev, u8 *__restrict__ out,
                                                                  const u64 *__restrict__ tied_count, u64 tied_cap, u64 *__restrict__ tpos, u64 *__restrict__ thead,
@@ -106,10 +127,10 @@ __global__ __launch_bounds__(256) void wide_bucket_finish_kernel(const u32 *__re
         const u64 hm = headw[w], km = keepw[w], pr = pre[w];
         const u64 below = lane == 63 ? hm : hm & ((2ull << lane) - 1ull);
         const u64 hloc = below ? (w << 6) + (u64)(63 - __clzll((long long)below)) : (pr >> 32);
-        const u64 p = (u64)V[i] | ((u64)S[i] << 32);
+        const u64 p = (u64)V[i] | ((CARRY ? K[i] >> WIDE_HI_SHIFT : (u64)S[i]) << 32);
         const u64 r = base + hloc;
         rank64[p] = r;
-        out[base + i] = prev(p);
+        out[base + i] = CARRY ? S[i] : prev(p);
         if ((km >> lane) & 1ull) {
             const u64 t = tbase + (u64)(u32)pr + (u64)__popcll(km & lanemask_lt());
             if (t < tied_cap) { tpos[t] = p; thead[t] = r; }
@@ -207,13 +228,14 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     u64 sort_max = Mb > seg ? Mb : seg;                            // largest sort or scan through tile_hist / scan_temp:
     if (sort_max < LYN_CAND_CAP) sort_max = LYN_CAND_CAP;          // a bucket, a segment, or the factor candidates
     // ---- arena layout -------------------------------------------------------------------------------------------------
-    const size_t need = align_up(n * 8, 256) + align_up(seg * 8, 256) + align_up((tiles + 1) * 8, 256) + scan_temp_bytes(n) +
+    const size_t need = align_up(n * 8, 256) + align_up(seg * 8, 256) + align_up(seg, 256) + align_up((tiles + 1) * 8, 256) + scan_temp_bytes(n) +
                         2 * align_up(Mb * 8, 256) + 2 * align_up(Mb * 4, 256) + 4 * align_up(Mb, 256) + radix_tile_hist_bytes(sort_max) +
                         scan_temp_bytes(sort_max) + 3 * align_up(mwords * 8, 256) + 8 * align_up(LYN_CAND_CAP * 8, 256) +
                         align_up(nseg * WIDE_PREFIXES * 4, 256) + (1 << 16);
     BWTS_TRY(arena_reserve(ctx, need));
     u64 *rank64 = arena_array<u64>(ctx, n);
     u64 *segkeys = arena_array<u64>(ctx, seg);
+    u8 *segprev = arena_array<u8>(ctx, seg);
     u64 *tile_min = arena_array<u64>(ctx, tiles + 1);
     void *pre_temp = arena_alloc(ctx, scan_temp_bytes(n));
     u64 *bk[2] = {arena_array<u64>(ctx, Mb), arena_array<u64>(ctx, Mb)};
@@ -226,7 +248,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     u32 *cvals[2] = {arena_array<u32>(ctx, LYN_CAND_CAP), arena_array<u32>(ctx, LYN_CAND_CAP)};
     u64 *fstart = arena_array<u64>(ctx, LYN_CAND_CAP);
     u32 *d_hist = arena_array<u32>(ctx, nseg * WIDE_PREFIXES);
-    if (!rank64 || !segkeys || !tile_min || !pre_temp || !bk[1] || !bv[1] || !bs_src || !bs_buf[1] || !bs_fin || !tile_hist || !scan_temp ||
+    if (!rank64 || !segkeys || !segprev || !tile_min || !pre_temp || !bk[1] || !bv[1] || !bs_src || !bs_buf[1] || !bs_fin || !tile_hist || !scan_temp ||
         !headw || !keepw || !prew || !cand[1] || !cvals[1] || !fstart || !d_hist)
         return BWTS_E_NOMEM;
 
@@ -320,16 +342,23 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     }
     ctx->tm.factors = k;
     const PrevSym64 prev{d_T, n, fstart, k};
+    static const bool carry_ok = [] { const char *e = getenv("BWTS_WIDE_CARRY"); return !(e && atoi(e) == 0); }();
+    // the output byte travels with the sort (see WideFilterOut): the passes cover whole bytes of the key, so the parked bits must lie above them
+    const bool carry = carry_ok && 8 * ((al.key_bits + 7) / 8) <= WIDE_HI_SHIFT;
 
     // cyclic round-0 keys of one segment: keybuild + the wrap-around patch near the factor ends
     auto seg_keys = [&](u64 s) -> int {
         const u64 p0 = s * seg, c = seg_count(s);
-        BWTS_TRY(launch_keybuild0_seg(ctx, d_T, n, al, segkeys, nullptr, false, p0, c));
+        BWTS_TRY(launch_keybuild0_seg(ctx, d_T, n, al, segkeys, nullptr, false, p0, c, carry ? segprev : nullptr));
         const int span = al.varlen ? 64 : al.msym - 1;
         if (span > 0) {
             const u64 threads = k * (u64)span;
             cyclic_patch_wide_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream>>>(
                 d_T, n, d_codes, al.bits, al.msym, d_vtab, al.key_bits, span, fstart, k, segkeys, p0, p0 + c);
+            HIPC(hipGetLastError());
+        }
+        if (carry) {
+            wide_head_prev_kernel<<<dim3((unsigned)((k + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_T, n, fstart, k, segprev, p0, p0 + c);
             HIPC(hipGetLastError());
         }
         return BWTS_OK;
@@ -390,7 +419,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
             const u64 c = seg_count(s);
             SpanGuard g(ctx, BWTS_K_RERANK, c, 9 * c + 13 * share);
             WideFilterIn fin{segkeys, pshift, plo, phi};
-            WideFilterOut fout{segkeys, pshift, plo, phi, s * seg, bk[0] + off, bv[0] + off, bs_src + off};
+            WideFilterOut fout{segkeys, pshift, plo, phi, s * seg, bk[0] + off, bv[0] + off, bs_src + off, carry ? segprev : nullptr};
             BWTS_TRY((device_scan<false, u32>(ctx, c, fin, fout, OpAdd(), 0u, scan_temp)));
             off += share;
         }
@@ -407,7 +436,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
             SpanGuard g(ctx, BWTS_K_RERANK, m, 8 * m);
             u64 waves = (words + GF_WORDS - 1) / GF_WORDS;
             unsigned blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
-            group_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], m, headw, keepw);
+            group_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], m, headw, keepw, carry ? (1ull << WIDE_HI_SHIFT) - 1ull : ~0ull);
             WordIn win{headw, keepw};
             ScanStoreArr<u64> wout{prew};
             BWTS_TRY((device_scan<false, u64>(ctx, words, win, wout, OpHeadCount(), (u64)0, scan_temp)));
@@ -415,8 +444,12 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
         {
             SpanGuard g(ctx, BWTS_K_EMIT, m, 15 * m);
             u64 blocks = (m + 255) / 256; if (blocks > 16384) blocks = 16384;
-            wide_bucket_finish_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.vals[res], bs_fin, m, base, headw, keepw, prew, rank64, prev,
-                                                                                            d_out, d_tied, tied_cap, tpos[0], thead[0], d_over);
+            if (carry)
+                wide_bucket_finish_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], sp.vals[res], bs_fin, m, base, headw, keepw, prew,
+                                                                                                      rank64, prev, d_out, d_tied, tied_cap, tpos[0], thead[0], d_over);
+            else
+                wide_bucket_finish_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], sp.vals[res], bs_fin, m, base, headw, keepw, prew,
+                                                                                                       rank64, prev, d_out, d_tied, tied_cap, tpos[0], thead[0], d_over);
             wide_add_tied_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(keepw, prew, words, d_tied);
             HIPC(hipGetLastError());
         }
