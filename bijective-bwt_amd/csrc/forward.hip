@@ -1567,7 +1567,20 @@ __global__ __launch_bounds__(DG_THREADS) void dense_round_kernel(const u32 *__re
         u32 less = 0, eq = 0, eq_before = 0;
         if (NKEYS == 3) {
             const u64 mine23 = my_key23[NKEYS == 3 ? j : 0];
-            for (u32 m = 0; m < sz; m++) {
+            u32 m = 0;
+            for (; m + 4 <= sz; m += 4) {              // four members' keys in flight (groups of up to DG_CAP members are ordered here)
+                u32 ko[4]; u64 ko23[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { ko[q] = key[gs + m + q]; ko23[q] = key23[NKEYS == 3 ? gs + m + q : 0]; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool same = ko[q] == mine && ko23[q] == mine23;
+                    less += (ko[q] < mine || (ko[q] == mine && ko23[q] < mine23)) ? 1u : 0u;
+                    eq += same ? 1u : 0u;
+                    eq_before += (same && gs + m + q < sl) ? 1u : 0u;
+                }
+            }
+            for (; m < sz; m++) {
                 const u32 ko = key[gs + m];
                 const u64 ko23 = key23[NKEYS == 3 ? gs + m : 0];
                 const bool same = ko == mine && ko23 == mine23;
