@@ -18,7 +18,7 @@ def line(tag, dt, t):
     print("%-34s wall %7.1f ms = %6.2f GB/s  (h2d %6.1f  device %6.1f  d2h %6.1f)" % (tag, 1e3 * dt, n / 1e9 / dt, t.h2d_ms, t.total_ms, t.d2h_ms), flush=True)
 
 x = None
-for threads in (6, 1, 2, 4, 8, 12):
+for threads in [int(v) for v in os.environ.get("BWTS_SWEEP_THREADS", "6,1,2,4,8,12").split(",")]:
     os.environ["BWTS_COPY_THREADS"] = str(threads)
     ctx = pkg.Context(0)
     if x is None:
