@@ -197,6 +197,35 @@ def test_deep_repeats_vs_oracle(ctx):
     assert np.array_equal(ctx.inverse(y), x)
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_dense_rounds_repeated_material(ctx, kind):
+    """4 MiB built from repeated material (tools/stress_dense.py): phrases pasted thousands of times (groups far larger than the LDS
+    cap: two sorts and regrouping on both key words), nested block copies, runs of one symbol, periodic stretches."""
+    rng = np.random.default_rng(71000 + kind)
+    n, sigma = 4 << 20, [4, 96, 2, 20][kind]
+    x = rng.integers(0, sigma, size=n, dtype=np.uint8)
+    if kind == 0:
+        for _ in range(5):
+            L = int(2 ** rng.uniform(3, 9)); ph = rng.integers(0, sigma, size=L, dtype=np.uint8)
+            for at in rng.integers(0, n - L, size=int(rng.integers(300, 20000))): x[at:at + L] = ph
+    elif kind == 1:
+        for _ in range(8):
+            L = int(2 ** rng.uniform(10, 20)); src = int(rng.integers(0, n - L)); dst = int(rng.integers(0, n - L))
+            x[dst:dst + L] = x[src:src + L].copy()
+        x[rng.integers(0, n, size=100)] = rng.integers(0, sigma, size=100, dtype=np.uint8)
+    elif kind == 2:
+        for _ in range(1500):
+            L = int(2 ** rng.uniform(2, 14)); at = int(rng.integers(0, n - L)); x[at:at + L] = rng.integers(0, sigma)
+    else:
+        for _ in range(100):
+            per = rng.integers(0, sigma, size=int(rng.integers(1, 40)), dtype=np.uint8)
+            L = int(2 ** rng.uniform(6, 18)); at = int(rng.integers(0, n - L)); x[at:at + L] = np.resize(per, L)
+    y = ctx.forward(x)
+    assert ctx.timings().active_after_round0 > n // 64
+    assert np.array_equal(y, O.forward(x))
+    assert np.array_equal(ctx.inverse(y), x)
+
+
 def test_dense_ties_large_vs_oracle(ctx):
     """n >= 2^22 with most elements tied after round 0: the dense rank array is built by the binned scatter."""
     block = O.generate("zipf", 1 << 21, 5)
@@ -740,7 +769,7 @@ def test_text_1GiB_properties(ctx):
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_alternate_paths(env):
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
-           "-k", "(small or mid_size or deep_repeats or dense_ties or text_16MiB or reference_unbwts_vectors_through_cabi) and not alternate"]
+           "-k", "(small or mid_size or deep_repeats or dense_ties or dense_rounds or text_16MiB or reference_unbwts_vectors_through_cabi) and not alternate"]
     # (-k matches case-insensitively and looks at parameter ids too: without the exclusion, an id like BWTS_RX_SMALL=0
     # makes the child select this very test and start a child of its own.)
     if os.environ.get("BWTS_TEST_CHILD"):
