@@ -173,7 +173,14 @@ __device__ __forceinline__ u32 symbol_of(const u64 *Ctab, u32 y)
 #define MARK_LOG 0
 #define MARK_SENTINEL 1
 #define MARK_BYTEMAP 2
-template <int MARK>
+#define MARK_MOMENTS 3
+//   3  moments     -- nothing is written per step: the workgroup keeps, per range of 2^shift indices (at most MOM_BUCKETS ranges),
+//                     how many it visited, the sum of their offsets and the sum of their squares (three LDS atomics).  A range that
+//                     misses one or two indices names them by arithmetic; a range that misses more is searched element by element
+//                     (moments_chase_kernel: an element is unreached iff its own chase returns to it before it meets a splitter).
+//                     The micro-benchmark puts the log at 7 % of the walk, and its scan at 1.4 ms (tools/micro/walk_steps.hip).
+#define MOM_BUCKETS 1024
+template <int MARK, int SBW = 16 /* registers of recorded symbols per store: 16 = 64-byte blocks, 4 = 16-byte ones (BWTS_WALK_SYMS=16) */>
 __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, u8 *__restrict__ marks, u32 *__restrict__ idxlog, u64 s, u64 node_cap, int g, u32 slot,
                                                           const u64 *__restrict__ Cg, u8 *__restrict__ seg,
                                                           uint4 *__restrict__ noderec /* x next node, y segment length, z smallest element, w its offset */,
@@ -181,9 +188,13 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                                                           unsigned long long *__restrict__ vcount,
                                                           unsigned long long *__restrict__ overflow,
                                                           unsigned long long *__restrict__ chunk_ctr, u32 *__restrict__ chunk_fill, u64 log_chunks,
-                                                          u32 nbuckets, u32 *__restrict__ bucket_seen)
+                                                          u32 nbuckets, u32 *__restrict__ bucket_seen,
+                                                          int mom_shift = 0, unsigned long long *__restrict__ mom = nullptr /* [3][MOM_BUCKETS]: counts, sums, sums of squares */)
 {
     __shared__ u64 Ctab[257];
+    __shared__ u32 mcnt[MARK == MARK_MOMENTS ? MOM_BUCKETS : 1];
+    __shared__ unsigned long long msum[MARK == MARK_MOMENTS ? MOM_BUCKETS : 1], msq[MARK == MARK_MOMENTS ? MOM_BUCKETS : 1];
+    if (MARK == MARK_MOMENTS) for (u32 b = threadIdx.x; b < MOM_BUCKETS; b += 256) { mcnt[b] = 0; msum[b] = 0; msq[b] = 0; }
     // MARK_LOG: how many indices of each 2^IDX_RANGE_LOG2-range this workgroup visited.  A range that ends up with all of
     // its indices counted holds nothing unvisited, and its log entries need not be looked at again.
     __shared__ u32 bseen[MARK == MARK_LOG ? IDX_MAX_BUCKETS : 1];
@@ -194,7 +205,13 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
     bool have = false, done = false;
     u64 my = 0;
     u32 x = 0, len = 0, mn = 0, mnoff = 0;
-    u32 sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;     // 16 recorded symbols waiting for one 16-byte store
+    // 64 recorded symbols wait in 16 registers for one 64-byte store into the node's slot (four 16-byte words at once): with 16 symbols
+    // per store the walk ran at 36 G steps/s, with 64 at 40 (tools/micro/walk_steps.hip: the scattered 16-byte stores cost 19 % of a bare chase,
+    // the 64-byte ones 3 %)
+    u32 sb[SBW];
+    constexpr u32 SBM = 4 * SBW - 1;           // symbols per block - 1
+#pragma unroll
+    for (int q = 0; q < SBW; q++) sb[q] = 0;
     u64 bnext = 0, bend = 0;            // the wave's current batch of splitter ids (wave-uniform)
     bool exhausted = false;
 #ifdef WALK_PROFILE
@@ -220,7 +237,11 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
             }
             if (!have && !done) {
                 const u64 id = bnext + (u64)__popcll(need & lanemask_lt());
-                if (id < bend) { have = true; my = id; x = (u32)(my << g); len = 0; mn = x; mnoff = 0; sb0 = sb1 = sb2 = sb3 = 0; }
+                if (id < bend) {
+                    have = true; my = id; x = (u32)(my << g); len = 0; mn = x; mnoff = 0;
+#pragma unroll
+                    for (int q = 0; q < SBW; q++) sb[q] = 0;
+                }
                 else if (exhausted) done = true;      // no work left anywhere: this lane never asks again
             }
             const u64 taken = bnext + (u64)__popcll(need);
@@ -248,25 +269,38 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                 lcur += na;
             }
         }
+        if (MARK == MARK_MOMENTS && have) {
+            const u32 b = x >> mom_shift;
+            const unsigned long long o = x & ((1u << mom_shift) - 1u);
+            atomicAdd(&mcnt[b], 1u); atomicAdd(&msum[b], o); atomicAdd(&msq[b], o * o);
+        }
         if (have) {
             const u32 y = LF[x];
             if (MARK == MARK_BYTEMAP) marks[x] = 1;
             else if (MARK == MARK_SENTINEL) LF[x] = LF_VISITED;       // the entry is not needed again
             {
                 const u32 sh = symbol_of(Ctab, y) << (8 * (len & 3u));
-                const u32 w = (len >> 2) & 3u;
-                sb0 |= w == 0 ? sh : 0u; sb1 |= w == 1 ? sh : 0u; sb2 |= w == 2 ? sh : 0u; sb3 |= w == 3 ? sh : 0u;
+                const u32 w = (len >> 2) & (u32)(SBW - 1);
+#pragma unroll
+                for (int q = 0; q < SBW; q++) sb[q] |= w == (u32)q ? sh : 0u;
             }
-            if ((len & 15u) == 15u) {
-                *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);
-                sb0 = sb1 = sb2 = sb3 = 0;
+            if ((len & SBM) == SBM) {                        // (only reached when the slot holds at least a block)
+                uint4 *d = (uint4 *)(seg + my * slot + (len & ~SBM));
+#pragma unroll
+                for (int q = 0; q < SBW / 4; q++) d[q] = make_uint4(sb[4 * q], sb[4 * q + 1], sb[4 * q + 2], sb[4 * q + 3]);
+#pragma unroll
+                for (int q = 0; q < SBW; q++) sb[q] = 0;
             }
             len++;
             x = y;
             const bool at_splitter = (x & gmask) == 0;
             if (at_splitter || len == slot) {
-                if (len & 15u)                                                                               // slot is a multiple of 16
-                    *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);
+                if (len & SBM) {                                                                             // slot is a multiple of 16
+                    uint4 *d = (uint4 *)(seg + my * slot + (len & ~SBM));
+                    const u32 rem = len & SBM;
+#pragma unroll
+                    for (int q = 0; q < SBW / 4; q++) if ((u32)q * 16u < rem) d[q] = make_uint4(sb[4 * q], sb[4 * q + 1], sb[4 * q + 2], sb[4 * q + 3]);
+                }
                 u64 next_node;
                 if (at_splitter) {
                     next_node = x >> g;
@@ -276,7 +310,11 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                     if (next_node >= node_cap) { atomicAdd(overflow, 1ull); next_node = node_cap - 1; }
                 }
                 noderec[my] = make_uint4((u32)next_node, len, mn, mnoff);
-                if (!at_splitter) { my = next_node; len = 0; mn = x; mnoff = 0; sb0 = sb1 = sb2 = sb3 = 0; }
+                if (!at_splitter) {
+                    my = next_node; len = 0; mn = x; mnoff = 0;
+#pragma unroll
+                    for (int q = 0; q < SBW; q++) sb[q] = 0;
+                }
             } else if (x < mn) { mn = x; mnoff = len; }
         }
     }
@@ -284,6 +322,13 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
     if (MARK == MARK_LOG) {
         __syncthreads();                  // every wave leaves the loop (the pool runs dry for all of them)
         for (u32 b = threadIdx.x; b < nbuckets; b += 256) { const u32 c = bseen[b]; if (c) atomicAdd(&bucket_seen[b], c); }
+    }
+    if (MARK == MARK_MOMENTS) {
+        __syncthreads();
+        for (u32 b = threadIdx.x; b < MOM_BUCKETS; b += 256) {
+            const u32 c = mcnt[b];
+            if (c) { atomicAdd(&mom[b], (unsigned long long)c); atomicAdd(&mom[MOM_BUCKETS + b], msum[b]); atomicAdd(&mom[2 * MOM_BUCKETS + b], msq[b]); }
+        }
     }
 #ifdef WALK_PROFILE
     if (lane_id() == 0) { atomicMax(&prof[2], (unsigned long long)wall_clock64()); atomicMin(&prof[4], (unsigned long long)wall_clock64()); }
@@ -644,6 +689,89 @@ __global__ __launch_bounds__(256) void lr2_distribute_kernel(const uint4 *__rest
 }
 
 // ------------------------------------------------------------------------------------
+// MARK_MOMENTS: the unreached elements from the ranges' counts, sums and sums of squares
+// ------------------------------------------------------------------------------------
+// One thread per range.  missing = size - count; one missing index: its offset is (sum of all offsets) - (sum seen); two: their sum A and
+// the sum of their squares B give (o1 - o2)^2 = 2 B - A^2.  More: the range goes onto the list for moments_chase_kernel.
+// counters: [1] unreached elements (as for the other marks), [10] listed ranges, [11] the arithmetic did not come out (fall back to the log)
+__global__ __launch_bounds__(MOM_BUCKETS) void moments_solve_kernel(const unsigned long long *__restrict__ mom, u64 n, int shift, const u32 *__restrict__ LF,
+                                                                    u32 *__restrict__ uidx, u32 *__restrict__ ulf, u64 ucap, u32 *__restrict__ def_list,
+                                                                    unsigned long long *__restrict__ counters)
+{
+    const u64 b = threadIdx.x;
+    const u64 lo = b << shift;
+    if (lo >= n) return;
+    const u64 size = n - lo < (1ull << shift) ? n - lo : (1ull << shift);
+    const u64 cnt = mom[b];
+    if (cnt > size) { atomicAdd(&counters[11], 1ull); return; }
+    const u64 d = size - cnt;
+    if (d == 0) return;
+    // sums over all offsets 0 .. size - 1 (mod 2^64: the differences below are small and come out exact)
+    const u64 sall = size * (size - 1) / 2;
+    const u64 a3 = size - 1, b3 = size, c3 = 2 * size - 1;                 // (size-1) size (2 size - 1) / 6, dividing before the products overflow
+    u64 f[3] = {a3, b3, c3};
+    { int two = 0, three = 0; for (int i = 0; i < 3; i++) { if (!two && f[i] % 2 == 0) { f[i] /= 2; two = 1; } } for (int i = 0; i < 3; i++) { if (!three && f[i] % 3 == 0) { f[i] /= 3; three = 1; } } }
+    const u64 qall = f[0] * f[1] * f[2];
+    const u64 A = sall - mom[MOM_BUCKETS + b], B = qall - mom[2 * MOM_BUCKETS + b];
+    if (d == 1) {
+        if (A >= size || A * A != B) { atomicAdd(&counters[11], 1ull); return; }
+        const unsigned long long at = atomicAdd(&counters[1], 1ull);
+        if (at < ucap) { const u32 x = (u32)(lo + A); uidx[at] = x; ulf[at] = LF[x]; }
+    } else if (d == 2) {
+        const u64 D = 2 * B - A * A;                                         // (o1 - o2)^2
+        u64 r = (u64)sqrt((double)D);
+        while (r * r > D) r--;
+        while ((r + 1) * (r + 1) <= D) r++;
+        const u64 o1 = (A - r) / 2, o2 = (A + r) / 2;
+        if (r * r != D || r == 0 || ((A - r) & 1) || o2 >= size || o1 * o1 + o2 * o2 != B) { atomicAdd(&counters[11], 1ull); return; }
+        const unsigned long long at = atomicAdd(&counters[1], 2ull);
+        if (at < ucap) { const u32 x = (u32)(lo + o1); uidx[at] = x; ulf[at] = LF[x]; }
+        if (at + 1 < ucap) { const u32 x = (u32)(lo + o2); uidx[at + 1] = x; ulf[at + 1] = LF[x]; }
+    } else {
+        const unsigned long long at = atomicAdd(&counters[10], 1ull);
+        def_list[at] = (u32)b;
+    }
+}
+// (own launch, after the one above: all ranges are listed) more elements to search than the budget allows: fall back to the log instead
+__global__ void moments_budget_kernel(unsigned long long *__restrict__ counters, int shift, u64 budget)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (counters[10] << shift) > budget) { counters[11] += 1; counters[10] = 0; }
+}
+// every element of the listed ranges follows LF until it stands on a splitter (a walk came through it: reached) or on itself
+// (its cycle holds no splitter: unreached).  `cap` steps without either: counters[11] (the caller falls back to the log).
+__global__ __launch_bounds__(256) void moments_chase_kernel(const u32 *__restrict__ def_list, const unsigned long long *__restrict__ counters_in, u64 n, int shift, int g,
+                                                            const u32 *__restrict__ LF, u32 cap, u32 *__restrict__ uidx, u32 *__restrict__ ulf, u64 ucap,
+                                                            unsigned long long *__restrict__ counters)
+{
+    const u64 ranges = counters_in[10];
+    const u64 per = (1ull << shift) / 256 ? (1ull << shift) / 256 : 1;      // 256-element pieces per range
+    const u32 gmask = (1u << g) - 1u;
+    for (u64 w = blockIdx.x; w < ranges * per; w += gridDim.x) {
+        const u64 x0 = ((u64)def_list[w / per] << shift) + (w % per) * 256 + threadIdx.x;
+        bool un = false;
+        if (x0 < n && (threadIdx.x < (1u << shift) || shift >= 8)) {
+            if ((x0 & gmask) != 0) {                                         // a splitter is where a walk starts: reached
+                u32 y = LF[x0], steps = 0;
+                for (;;) {
+                    if (y == (u32)x0) { un = true; break; }
+                    if ((y & gmask) == 0) break;
+                    if (++steps > cap) { atomicAdd(&counters[11], 1ull); break; }
+                    y = LF[y];
+                }
+            }
+        }
+        const u64 m = __ballot(un);
+        if (m) {
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            unsigned long long bse = 0;
+            if (lane_id() == leader) bse = atomicAdd(&counters[1], (unsigned long long)__popcll(m));
+            bse = shfl_t((u64)bse, leader);
+            if (un) { const u64 at = bse + (u64)__popcll(m & lanemask_lt()); if (at < ucap) { uidx[at] = (u32)x0; ulf[at] = LF[x0]; } }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // cycles without a splitter (elements no walk reached)
 // ------------------------------------------------------------------------------------
 // Natural inputs leave a few dozen such elements (tiny Lyndon factors); a constant or sorted input leaves nearly all n
@@ -781,10 +909,14 @@ __global__ __launch_bounds__(256) void unit_ends_kernel(const u32 *__restrict__ 
 
 // One attempt with splitter spacing 2^g.  *retry is set when the node pool overflows (adversarial LF) or the unreached
 // elements are too many for the unit-node ranking; the caller then repeats with g = 0 (every element a splitter).
-static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int g, int mark, bool *retry, bool *ambiguous)
+static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int g, int mark, bool *retry, bool *ambiguous, bool *need_log = nullptr)
 {
     *retry = false;
     *ambiguous = false;
+    if (need_log) *need_log = false;
+    const bool moments = mark == MARK_MOMENTS;
+    int mom_shift = 0;
+    while (((n + (1ull << mom_shift) - 1) >> mom_shift) > MOM_BUCKETS) mom_shift++;
     const u64 G = 1ull << g;
     const u64 s = (n + G - 1) / G;
     const u64 tiles = (n + LF_TILE - 1) / LF_TILE;
@@ -801,8 +933,11 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     BWTS_TRY(arena_reserve(ctx, align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + inverse_node_bytes(node_cap, slot) +
                                     align_up(n, 256) +
                                     (mark == MARK_LOG ? align_up(log_chunks * IDX_CHUNK * 4, 256) + align_up(log_chunks * 4, 256) + align_up(n * 4 + (4ull << IDX_RANGE_LOG2), 256) + (1 << 20) : 0) +
-                                    (1 << 16)));
+                                    (1 << 17)));
     u32 *LF = arena_array<u32>(ctx, n);
+    unsigned long long *mom = moments ? (unsigned long long *)arena_array<u64>(ctx, 3 * MOM_BUCKETS) : nullptr;
+    u32 *def_list = moments ? arena_array<u32>(ctx, MOM_BUCKETS) : nullptr;
+    if (moments && (!mom || !def_list)) return BWTS_E_NOMEM;
     u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
     void *scan_temp = arena_alloc(ctx, scan_temp_bytes(n));
     uint4 *noderec = arena_array<uint4>(ctx, node_cap);
@@ -856,14 +991,23 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         HIPC(hipMemsetAsync(chunk_fill, 0, log_chunks * sizeof(u32), ctx->stream));
         HIPC(hipMemsetAsync(bucket_seen, 0, IDX_MAX_BUCKETS * sizeof(u32), ctx->stream));
     }
+    if (moments) HIPC(hipMemsetAsync(mom, 0, 3 * MOM_BUCKETS * sizeof(u64), ctx->stream));
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 6 * n);
-        if (mark == MARK_BYTEMAP)
+        static const bool syms16 = [] { const char *e = getenv("BWTS_WALK_SYMS"); return e && atoi(e) == 16; }();      // 16-byte symbol stores (A/B against the 64-byte ones)
+        if (moments)
+            walk_record_kernel<MARK_MOMENTS><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
+                                                                                          ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen,
+                                                                                          mom_shift, mom);
+        else if (mark == MARK_BYTEMAP)
             walk_record_kernel<MARK_BYTEMAP><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
                                                                                           ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         else if (mark == MARK_SENTINEL)
             walk_record_kernel<MARK_SENTINEL><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
                                                                                            ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
+        else if (syms16)
+            walk_record_kernel<MARK_LOG, 4><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
+                                                                                         ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         else
             walk_record_kernel<MARK_LOG><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
                                                                                       ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
@@ -900,7 +1044,13 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     BWTS_TRY(lay_out_lists(ucap));
     auto collect_unreached = [&](bool first_time) -> int {
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
-        if (mark == MARK_LOG) {
+        if (moments) {
+            if (!first_time) HIPC(hipMemsetAsync(ticket + 10, 0, 2 * sizeof(u64), ctx->stream));
+            const u64 budget = (4ull << 20) > (1ull << mom_shift) ? (4ull << 20) : (1ull << mom_shift);        // elements the search may look at
+            moments_solve_kernel<<<dim3(1), dim3(MOM_BUCKETS), 0, ctx->stream>>>(mom, n, mom_shift, LF, uidx, ulf, ucap, def_list, ticket);
+            moments_budget_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(ticket, mom_shift, budget);
+            moments_chase_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(def_list, ticket, n, mom_shift, g, LF, 1u << 16, uidx, ulf, ucap, ticket);
+        } else if (mark == MARK_LOG) {
             const int bm_bytes = (int)((1u << IDX_RANGE_LOG2) / 8);
             if (first_time) {
                 HIPC(hipMemsetAsync(bucket_fill, 0, (size_t)nbuckets * IDX_FILL_STRIDE * sizeof(u32), ctx->stream));
@@ -934,6 +1084,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
     const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
     const u64 nu2 = ctx->h_small[SMI_COUNTERS + 6];
+    if (moments && ctx->h_small[SMI_COUNTERS + 11]) {          // the ranges' moments do not name the unreached elements: the index log does
+        if (need_log) *need_log = true;
+        return BWTS_OK;
+    }
     ctx->tm.unvisited = nu;
     if (nu > n || nu2 > s_all) return BWTS_E_INTERNAL;
     ctx->unv_hint = (size_t)nu;
@@ -1068,19 +1222,25 @@ int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     static const int force_wide = [] { const char *e = getenv("BWTS_FORCE_WIDE"); return e ? atoi(e) : 0; }();
     if (n > 0x100000000ull || force_wide) return inverse_wide_impl(ctx, d_in, n, d_out);
     bool retry = false, ambiguous = false;
-    // how visited entries are recorded: index log (default), or the two mark forms (BWTS_INV_MARK=sentinel|bytemap,
-    // BWTS_BYTEMARK=1: tests, and the fallback chain below)
-    int mark = MARK_LOG;
+    // how the unreached elements are found: per-range moments (default; falls back to the index log when too many are missing),
+    // the index log, or the two mark forms (BWTS_INV_MARK=log|sentinel|bytemap, BWTS_BYTEMARK=1: tests, and the fallback chain below)
+    int mark = MARK_MOMENTS;
     const char *me = getenv("BWTS_INV_MARK");
+    if (me && !strcmp(me, "log")) mark = MARK_LOG;
     if (me && !strcmp(me, "sentinel")) mark = MARK_SENTINEL;
     if ((me && !strcmp(me, "bytemap")) || getenv("BWTS_BYTEMARK")) mark = MARK_BYTEMAP;
-    BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous));
+    bool need_log = false;
+    BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous, &need_log));
+    if (need_log) {             // many unreached elements (low-entropy input): the walk again, this time logging every index it visits
+        mark = MARK_LOG;
+        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous));
+    }
     if (ambiguous) {            // sentinel marks only, n = 2^32: 0xffffffff was a real entry of a cycle without a splitter
         mark = MARK_BYTEMAP;
         BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous));
     }
     if (retry) {
-        if (mark == MARK_LOG) mark = MARK_SENTINEL;        // adversarial LF: keep the retry on the simplest marks
+        if (mark == MARK_LOG || mark == MARK_MOMENTS) mark = MARK_SENTINEL;        // adversarial LF: keep the retry on the simplest marks
         BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, mark, &retry, &ambiguous));
         if (ambiguous) BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, MARK_BYTEMAP, &retry, &ambiguous));
         if (retry || ambiguous) return BWTS_E_INTERNAL;

@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__rest
     bool have = false, done = false;
     u64 my = 0, x = 0, mn = 0;
     u32 len = 0, mnoff = 0;
-    u32 sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0;
+    u32 sb[16];                  // 64 recorded symbols, stored as one 64-byte block (see walk_record_kernel)
+#pragma unroll
+    for (int q = 0; q < 16; q++) sb[q] = 0;
     u64 bnext = 0, bend = 0;
     bool exhausted = false;
     for (;;) {
@@ -100,7 +102,11 @@ __global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__rest
             }
             if (!have && !done) {
                 const u64 id = bnext + (u64)__popcll(need & lanemask_lt());
-                if (id < bend) { have = true; my = id; x = my << WI_G_LOG2; len = 0; mn = x; mnoff = 0; sb0 = sb1 = sb2 = sb3 = 0; }
+                if (id < bend) {
+                    have = true; my = id; x = my << WI_G_LOG2; len = 0; mn = x; mnoff = 0;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) sb[q] = 0;
+                }
                 else if (exhausted) done = true;
             }
             const u64 taken = bnext + (u64)__popcll(need);
@@ -112,18 +118,27 @@ __global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__rest
             marks[x] = 1;
             {
                 const u32 sh = symbol_of64(Ctab, y) << (8 * (len & 3u));
-                const u32 w = (len >> 2) & 3u;
-                sb0 |= w == 0 ? sh : 0u; sb1 |= w == 1 ? sh : 0u; sb2 |= w == 2 ? sh : 0u; sb3 |= w == 3 ? sh : 0u;
+                const u32 w = (len >> 2) & 15u;
+#pragma unroll
+                for (int q = 0; q < 16; q++) sb[q] |= w == (u32)q ? sh : 0u;
             }
-            if ((len & 15u) == 15u) {
-                *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);
-                sb0 = sb1 = sb2 = sb3 = 0;
+            if ((len & 63u) == 63u) {
+                uint4 *d = (uint4 *)(seg + my * slot + (len & ~63u));
+#pragma unroll
+                for (int q = 0; q < 4; q++) d[q] = make_uint4(sb[4 * q], sb[4 * q + 1], sb[4 * q + 2], sb[4 * q + 3]);
+#pragma unroll
+                for (int q = 0; q < 16; q++) sb[q] = 0;
             }
             len++;
             x = y;
             const bool at_splitter = (x & gmask) == 0;
             if (at_splitter || len == slot) {
-                if (len & 15u) *(uint4 *)(seg + my * slot + (len & ~15u)) = make_uint4(sb0, sb1, sb2, sb3);
+                if (len & 63u) {
+                    uint4 *d = (uint4 *)(seg + my * slot + (len & ~63u));
+                    const u32 rem = len & 63u;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if ((u32)q * 16u < rem) d[q] = make_uint4(sb[4 * q], sb[4 * q + 1], sb[4 * q + 2], sb[4 * q + 3]);
+                }
                 u64 next_node;
                 if (at_splitter) { next_node = x >> WI_G_LOG2; have = false; }
                 else {
@@ -132,7 +147,11 @@ __global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__rest
                 }
                 WiNode nd; nd.nxt = (u32)next_node; nd.len = len; nd.mn = mn; nd.off = mnoff; nd.pad = 0;
                 nodes[my] = nd;
-                if (!at_splitter) { my = next_node; len = 0; mn = x; mnoff = 0; sb0 = sb1 = sb2 = sb3 = 0; }
+                if (!at_splitter) {
+                    my = next_node; len = 0; mn = x; mnoff = 0;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) sb[q] = 0;
+                }
             } else if (x < mn) { mn = x; mnoff = len; }
         }
     }

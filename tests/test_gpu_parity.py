@@ -763,6 +763,7 @@ def test_text_1GiB_properties(ctx):
     {"BWTS_DENSE": "legacy", "BWTS_SEGSORT": "0"},                            # later rounds: radix sort of the whole tied list instead of sorting small groups in place
     {"BWTS_RX_SMALL": "0"},                           # small sorts through the multi-launch passes instead of the one-workgroup kernel
     {"BWTS_K0DIR": "0"},                              # sparse key builder: plain binary searches, no directories                      # dense rank array by two plain scatters instead of the binned one
+    {"BWTS_INV_MARK": "log"},                         # inverse logs every visited index (the fallback of the per-range moments)
     {"BWTS_INV_MARK": "sentinel"},                    # inverse marks visited entries in place instead of logging them
     {"BWTS_BYTEMARK": "1"},                           # inverse marks in a byte map (the n = 2^32 fallback)
     {"BWTS_SPLIT_LOG2": "0"},                         # inverse: every element a splitter (plain pointer jumping)

@@ -3,6 +3,10 @@
 //   bit1  16-byte symbol store every 16 steps into a per-lane slot
 //   bit2  8-step binary search in an LDS table per step
 //   bit3  segment ends: a lane restarts from a fresh index every ~512 steps (data-dependent exit + 4 small stores)
+//   bit4  index log in lane-fixed form: a lane keeps four indices and stores them as one 16-byte word every fourth step -- the wave's
+//         store is one contiguous KB per four steps instead of 256 B every step
+//   bit5  symbol store in wave-coalesced form: every 16 steps all lanes store their 16 symbols side by side (one contiguous KB per wave)
+//         instead of 16 bytes each into slots of their own
 //   hipcc -O3 --offload-arch=gfx950 walk_steps.hip -o walk_steps && ./walk_steps
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -25,8 +29,17 @@ template <int F> __global__ __launch_bounds__(256) void chase(const u32 *__restr
     u32 x = mix(gid + 12345) & mask;
     u32 sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0, len = 0, restarts = 0;
     u64 lcur = wave * (u64)steps * 64;
+    u32 l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+    u32 big[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) big[q] = 0;
     for (int s = 0; s < steps; s++) {
         const u32 y = t[x];
+        if (F & 16) {
+            const int q = s & 3;
+            l0 = q == 0 ? x : l0; l1 = q == 1 ? x : l1; l2 = q == 2 ? x : l2; l3 = q == 3 ? x : l3;
+            if (q == 3) ((uint4 *)log)[(wave * (u64)(steps / 4) + (u64)(s >> 2)) * 64 + lane] = make_uint4(l0, l1, l2, l3);
+        }
         if (F & 1) {
             const u64 act = __ballot(true);
             log[lcur + __popcll(act & ((1ull << lane) - 1))] = x;
@@ -44,6 +57,23 @@ template <int F> __global__ __launch_bounds__(256) void chase(const u32 *__restr
             const u32 w = (len >> 2) & 3u;
             sb0 |= w == 0 ? sh : 0u; sb1 |= w == 1 ? sh : 0u; sb2 |= w == 2 ? sh : 0u; sb3 |= w == 3 ? sh : 0u;
             if ((len & 15u) == 15u) { seg[gid * (steps / 16 + 1) + (len >> 4)] = make_uint4(sb0, sb1, sb2, sb3); sb0 = sb1 = sb2 = sb3 = 0; }
+        } else if (F & 64) {       // per-lane slots as in bit1, but 64 symbols gathered in 16 registers and stored as four 16-byte words at once
+            const u32 sh = sym << (8 * (len & 3u));
+            const u32 w = (len >> 2) & 15u;
+#pragma unroll
+            for (int q = 0; q < 16; q++) big[q] |= w == (u32)q ? sh : 0u;
+            if ((len & 63u) == 63u) {
+                uint4 *d = seg + gid * (steps / 16 + 4) + (len >> 6) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; q++) d[q] = make_uint4(big[4 * q], big[4 * q + 1], big[4 * q + 2], big[4 * q + 3]);
+#pragma unroll
+                for (int q = 0; q < 16; q++) big[q] = 0;
+            }
+        } else if (F & 32) {
+            const u32 sh = sym << (8 * (s & 3));
+            const u32 w = (s >> 2) & 3;
+            sb0 |= w == 0 ? sh : 0u; sb1 |= w == 1 ? sh : 0u; sb2 |= w == 2 ? sh : 0u; sb3 |= w == 3 ? sh : 0u;
+            if ((s & 15) == 15) { seg[(wave * (u64)(steps / 16 + 1) + (u64)(s >> 4)) * 64 + lane] = make_uint4(sb0, sb1, sb2, sb3); sb0 = sb1 = sb2 = sb3 = 0; }
         } else sb0 += sym;
         len++;
         x = y;
@@ -56,6 +86,7 @@ template <int F> __global__ __launch_bounds__(256) void chase(const u32 *__restr
             }
         }
     }
+    if (F & 64) { for (int q = 0; q < 16; q++) sb0 += big[q]; }
     if (x == 0xffffffffu || sb0 == 0x12345) out[0] = x;
 }
 template <int F> void run(const u32 *t, u32 mask, u32 *out, u32 *log, uint4 *seg, u32 *nodes, int blocks, int steps)
@@ -91,7 +122,7 @@ int main(int argc, char **argv)
     const u64 lanes = (u64)blocks * 256;
     u32 *out, *t, *log, *nodes; uint4 *seg;
     CK(hipMalloc(&out, 4096)); CK(hipMalloc(&t, n * 4));
-    CK(hipMalloc(&log, lanes * steps * 4)); CK(hipMalloc(&seg, lanes * (steps / 16 + 1) * 16)); CK(hipMalloc(&nodes, lanes * 8 * 16));
+    CK(hipMalloc(&log, lanes * steps * 4)); CK(hipMalloc(&seg, lanes * (steps / 16 + 4) * 16)); CK(hipMalloc(&nodes, lanes * 8 * 16));
   for (int kind = 0; kind < 3; kind++) {
     printf("table kind %d (0 random function, 1 LF of uniform bytes, 2 LF of skewed bytes)\n", kind);
     if (kind == 0) { fill<<<8192, 256>>>(t, n, mask); CK(hipDeviceSynchronize()); } else build_lf(t, n, kind == 2);
@@ -104,6 +135,15 @@ int main(int argc, char **argv)
     run<6>(t, mask, out, log, seg, nodes, blocks, steps);
     run<7>(t, mask, out, log, seg, nodes, blocks, steps);
     run<15>(t, mask, out, log, seg, nodes, blocks, steps);
+    run<16>(t, mask, out, log, seg, nodes, blocks, steps);
+    run<32>(t, mask, out, log, seg, nodes, blocks, steps);
+    run<48>(t, mask, out, log, seg, nodes, blocks, steps);
+    run<33>(t, mask, out, log, seg, nodes, blocks, steps);
+    run<60>(t, mask, out, log, seg, nodes, blocks, steps);
+    run<45>(t, mask, out, log, seg, nodes, blocks, steps);
+    run<64>(t, mask, out, log, seg, nodes, blocks, steps);
+    run<65>(t, mask, out, log, seg, nodes, blocks, steps);
+    run<77>(t, mask, out, log, seg, nodes, blocks, steps);
   }
     return 0;
 }
