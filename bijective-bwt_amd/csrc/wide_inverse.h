@@ -2,9 +2,9 @@
 //
 // Same plan as the main path (unbwts.c:31-86 -> stable LF map, splitter walk that records every segment's symbols, ranking
 // of the reduced list, placement), with 64-bit element indices and without the main path's tuning: LF is a u64 array built
-// segment by segment (the tile table's offsets are 32-bit), visited entries are marked in a byte map, the reduced list
+// segment by segment (the tile table's offsets are 32-bit), the unreached elements come from per-range moments (a byte map as the fallback), the reduced list
 // (n / 256 nodes) is ranked by plain pointer jumping, and everything sized by node or cycle counts carries 64-bit positions.
-// Memory at n = 12 GiB: LF 96 GiB + marks 12 + recorded segments 58 + nodes ~6.
+// Memory at n = 12 GiB: LF 96 GiB + recorded segments 58 + nodes ~6 (+ marks 12 on the fallback).
 #define WI_G_LOG2 8
 #define WI_NIL 0xffffffffu
 
@@ -71,12 +71,20 @@ __global__ __launch_bounds__(LF_THREADS) void lf_rank_wide_kernel(const u8 *__re
 struct WiNode { u32 nxt, len; u64 mn; u32 off, pad; };
 
 // walk_record_kernel of the main path with 64-bit elements and byte-map marks (see there for the scheme)
+// MOM: no byte map; the unreached elements come from per-range moments (inverse.hip, MARK_MOMENTS) over WMOM_BUCKETS ranges kept in
+// dynamic LDS (80 KB: two workgroups per CU) -- the random byte write per step was what held this walk at half the main path's rate
+#define WMOM_BUCKETS 4096
+template <bool MOM>
 __global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__restrict__ LF, u8 *__restrict__ marks, u64 s, u64 node_cap, u32 slot,
                                                                const u64 *__restrict__ Cg, u8 *__restrict__ seg, WiNode *__restrict__ nodes,
                                                                unsigned long long *__restrict__ ticket, unsigned long long *__restrict__ vcount,
-                                                               unsigned long long *__restrict__ overflow)
+                                                               unsigned long long *__restrict__ overflow, int mom_shift, unsigned long long *__restrict__ mom)
 {
     __shared__ u64 Ctab[257];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long wmom_sm[];        // MOM: sums, sums of squares, counts
+    unsigned long long *msum = wmom_sm, *msq = wmom_sm + WMOM_BUCKETS;
+    u32 *mcnt = (u32 *)(wmom_sm + 2 * WMOM_BUCKETS);
+    if (MOM) for (u32 b = threadIdx.x; b < WMOM_BUCKETS; b += 256) { mcnt[b] = 0; msum[b] = 0; msq[b] = 0; }
     for (int i = threadIdx.x; i < 257; i += 256) Ctab[i] = Cg[i];
     __syncthreads();
     const u64 gmask = (1ull << WI_G_LOG2) - 1ull;
@@ -115,7 +123,11 @@ __global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__rest
         if (__ballot(have || !done) == 0) break;
         if (have) {
             const u64 y = LF[x];
-            marks[x] = 1;
+            if (MOM) {
+                const u32 b = (u32)(x >> mom_shift);
+                const unsigned long long o = x & ((1ull << mom_shift) - 1ull);
+                atomicAdd(&mcnt[b], 1u); atomicAdd(&msum[b], o); atomicAdd(&msq[b], o * o);
+            } else marks[x] = 1;
             {
                 const u32 sh = symbol_of64(Ctab, y) << (8 * (len & 3u));
                 const u32 w = (len >> 2) & 15u;
@@ -153,6 +165,83 @@ __global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__rest
                     for (int q = 0; q < 16; q++) sb[q] = 0;
                 }
             } else if (x < mn) { mn = x; mnoff = len; }
+        }
+    }
+    if (MOM) {
+        __syncthreads();                  // every wave leaves the loop (the pool runs dry for all of them)
+        for (u32 b = threadIdx.x; b < WMOM_BUCKETS; b += 256) {
+            const u32 c = mcnt[b];
+            if (c) { atomicAdd(&mom[b], (unsigned long long)c); atomicAdd(&mom[WMOM_BUCKETS + b], msum[b]); atomicAdd(&mom[2 * WMOM_BUCKETS + b], msq[b]); }
+        }
+    }
+}
+
+// moments_solve_kernel / moments_budget_kernel / moments_chase_kernel of the main path (inverse.hip) with 64-bit elements and WMOM_BUCKETS ranges
+__global__ __launch_bounds__(1024) void moments_solve_wide_kernel(const unsigned long long *__restrict__ mom, u64 n, int shift, const u64 *__restrict__ LF,
+                                                                  u64 *__restrict__ uidx, u64 *__restrict__ ulf, u64 ucap, u32 *__restrict__ def_list,
+                                                                  unsigned long long *__restrict__ counters)
+{
+    const u64 b = (u64)blockIdx.x * 1024 + threadIdx.x;
+    const u64 lo = b << shift;
+    if (b >= WMOM_BUCKETS || lo >= n) return;
+    const u64 size = n - lo < (1ull << shift) ? n - lo : (1ull << shift);
+    const u64 cnt = mom[b];
+    if (cnt > size) { atomicAdd(&counters[11], 1ull); return; }
+    const u64 d = size - cnt;
+    if (d == 0) return;
+    const u64 sall = size * (size - 1) / 2;
+    u64 f[3] = {size - 1, size, 2 * size - 1};
+    { int two = 0, three = 0; for (int i = 0; i < 3; i++) { if (!two && f[i] % 2 == 0) { f[i] /= 2; two = 1; } } for (int i = 0; i < 3; i++) { if (!three && f[i] % 3 == 0) { f[i] /= 3; three = 1; } } }
+    const u64 qall = f[0] * f[1] * f[2];                                     // mod 2^64, like the sums of squares it is compared with
+    const u64 A = sall - mom[WMOM_BUCKETS + b], B = qall - mom[2 * WMOM_BUCKETS + b];
+    if (d == 1) {
+        if (A >= size || A * A != B) { atomicAdd(&counters[11], 1ull); return; }
+        const unsigned long long at = atomicAdd(&counters[1], 1ull);
+        if (at < ucap) { const u64 x = lo + A; uidx[at] = x; ulf[at] = LF[x]; }
+    } else if (d == 2) {
+        const u64 D = 2 * B - A * A;
+        u64 r = (u64)sqrt((double)D);
+        while (r * r > D) r--;
+        while ((r + 1) * (r + 1) <= D) r++;
+        const u64 o1 = (A - r) / 2, o2 = (A + r) / 2;
+        if (A >= 2 * size || r * r != D || r == 0 || ((A - r) & 1) || o2 >= size || o1 * o1 + o2 * o2 != B) { atomicAdd(&counters[11], 1ull); return; }
+        const unsigned long long at = atomicAdd(&counters[1], 2ull);
+        if (at < ucap) { const u64 x = lo + o1; uidx[at] = x; ulf[at] = LF[x]; }
+        if (at + 1 < ucap) { const u64 x = lo + o2; uidx[at + 1] = x; ulf[at + 1] = LF[x]; }
+    } else {
+        const unsigned long long at = atomicAdd(&counters[10], 1ull);
+        def_list[at] = (u32)b;
+    }
+}
+__global__ __launch_bounds__(256) void moments_chase_wide_kernel(const u32 *__restrict__ def_list, const unsigned long long *__restrict__ counters_in, u64 n, int shift,
+                                                                 const u64 *__restrict__ LF, u32 cap, u64 *__restrict__ uidx, u64 *__restrict__ ulf, u64 ucap,
+                                                                 unsigned long long *__restrict__ counters)
+{
+    const u64 ranges = counters_in[10];
+    const u64 per = (1ull << shift) / 256 ? (1ull << shift) / 256 : 1;
+    const u64 gmask = (1ull << WI_G_LOG2) - 1ull;
+    for (u64 w = blockIdx.x; w < ranges * per; w += gridDim.x) {
+        const u64 x0 = ((u64)def_list[w / per] << shift) + (w % per) * 256 + threadIdx.x;
+        bool un = false;
+        if (x0 < n && (threadIdx.x < (1u << (shift < 8 ? shift : 8)) || shift >= 8)) {
+            if ((x0 & gmask) != 0) {
+                u64 y = LF[x0];
+                u32 steps = 0;
+                for (;;) {
+                    if (y == x0) { un = true; break; }
+                    if ((y & gmask) == 0) break;
+                    if (++steps > cap) { atomicAdd(&counters[11], 1ull); break; }
+                    y = LF[y];
+                }
+            }
+        }
+        const u64 m = __ballot(un);
+        if (m) {
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            unsigned long long bse = 0;
+            if (lane_id() == leader) bse = atomicAdd(&counters[1], (unsigned long long)__popcll(m));
+            bse = shfl_t((u64)bse, leader);
+            if (un) { const u64 at = bse + (u64)__popcll(m & lanemask_lt()); if (at < ucap) { uidx[at] = x0; ulf[at] = LF[x0]; } }
         }
     }
 }
@@ -381,9 +470,25 @@ struct ScopedDeviceBlock {
     ~ScopedDeviceBlock() { if (p) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(p); } }
 };
 
+static int inverse_wide_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, bool moments, bool *need_marks);
 static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
+    // unreached elements from per-range moments; the byte map when too many are missing (or BWTS_INV_MARK=bytemap / BWTS_BYTEMARK=1)
+    const char *me = getenv("BWTS_INV_MARK");
+    bool moments = !((me && !strcmp(me, "bytemap")) || getenv("BWTS_BYTEMARK"));
+    bool need_marks = false;
+    if (moments) {
+        BWTS_TRY(inverse_wide_attempt(ctx, d_in, n, d_out, true, &need_marks));
+        if (!need_marks) return BWTS_OK;
+    }
+    return inverse_wide_attempt(ctx, d_in, n, d_out, false, &need_marks);
+}
+static int inverse_wide_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, bool moments, bool *need_marks)
+{
+    *need_marks = false;
     if (n > (1ull << 36)) return BWTS_E_RANGE;
+    int mom_shift = 0;
+    while (((n + (1ull << mom_shift) - 1) >> mom_shift) > WMOM_BUCKETS) mom_shift++;
     const u64 G = 1ull << WI_G_LOG2;
     const u64 s = (n + G - 1) / G;
     const u32 slot = (u32)(4 * G);
@@ -395,10 +500,13 @@ static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     const u64 nseg = (n + segn - 1) / segn;
     const size_t need = align_up(n * 8, 256) + align_up(n, 256) + align_up(node_cap * slot, 256) + align_up(node_cap * sizeof(WiNode), 256) +
                         2 * align_up(node_cap * sizeof(WiMin), 256) + 2 * align_up(node_cap * sizeof(WiSum), 256) + 6 * align_up(node_cap * 8, 256) +
-                        align_up(node_cap * sizeof(WiCycle), 256) + radix_tile_hist_bytes(segn) + scan_temp_bytes(segn) + (1 << 16);
+                        align_up(node_cap * sizeof(WiCycle), 256) + radix_tile_hist_bytes(segn) + scan_temp_bytes(segn) + (1 << 18);
     BWTS_TRY(arena_reserve(ctx, need));
     u64 *LF = arena_array<u64>(ctx, n);
-    u8 *marks = arena_array<u8>(ctx, n);
+    u8 *marks = moments ? (u8 *)arena_alloc(ctx, 256) : arena_array<u8>(ctx, n);
+    unsigned long long *mom = (unsigned long long *)arena_array<u64>(ctx, 3 * WMOM_BUCKETS);
+    u32 *def_list = arena_array<u32>(ctx, WMOM_BUCKETS);
+    if (!mom || !def_list) return BWTS_E_NOMEM;
     u8 *seg = arena_array<u8>(ctx, node_cap * slot);
     WiNode *nodes = arena_array<WiNode>(ctx, node_cap);
     WiMin *wmin[2] = {arena_array<WiMin>(ctx, node_cap), arena_array<WiMin>(ctx, node_cap)};
@@ -449,12 +557,19 @@ static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 
     unsigned long long *ticket = (unsigned long long *)(ctx->d_small + SMI_COUNTERS);
     HIPC(hipMemsetAsync(ticket, 0, 16 * sizeof(u64), ctx->stream));
-    HIPC(hipMemsetAsync(marks, 0, n, ctx->stream));
+    if (moments) HIPC(hipMemsetAsync(mom, 0, 3 * WMOM_BUCKETS * sizeof(u64), ctx->stream));
+    else HIPC(hipMemsetAsync(marks, 0, n, ctx->stream));
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 10 * n);
         const u64 walkers = s < 524288 ? s : 524288;
-        walk_record_wide_kernel<<<dim3((unsigned)((walkers + 255) / 256)), dim3(256), 0, ctx->stream>>>(LF, marks, s, node_cap, slot, dC, seg, nodes, ticket,
-                                                                                                       ticket + 3, ticket + 4);
+        if (moments) {
+            constexpr size_t lds = (size_t)WMOM_BUCKETS * (8 + 8 + 4);
+            BWTS_TRY(ensure_dyn_lds(ctx, (const void *)walk_record_wide_kernel<true>, lds));
+            walk_record_wide_kernel<true><<<dim3((unsigned)((walkers + 255) / 256)), dim3(256), lds, ctx->stream>>>(LF, marks, s, node_cap, slot, dC, seg, nodes, ticket,
+                                                                                                                 ticket + 3, ticket + 4, mom_shift, mom);
+        } else
+            walk_record_wide_kernel<false><<<dim3((unsigned)((walkers + 255) / 256)), dim3(256), 0, ctx->stream>>>(LF, marks, s, node_cap, slot, dC, seg, nodes, ticket,
+                                                                                                                ticket + 3, ticket + 4, 0, nullptr);
         HIPC(hipGetLastError());
     }
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
@@ -479,8 +594,16 @@ static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     BWTS_TRY(lay_out(ucap));
     auto collect = [&]() -> int {
         SpanGuard sg(ctx, BWTS_K_OTHER, n, n);
-        u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
-        collect_unvisited_wide_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, ucap, ticket + 1);
+        if (moments) {
+            HIPC(hipMemsetAsync(ticket + 10, 0, 2 * sizeof(u64), ctx->stream));
+            const u64 budget = (8ull << 20) > (1ull << mom_shift) ? (8ull << 20) : (1ull << mom_shift);        // elements the search may look at
+            moments_solve_wide_kernel<<<dim3(WMOM_BUCKETS / 1024), dim3(1024), 0, ctx->stream>>>(mom, n, mom_shift, LF, uidx, ulf, ucap, def_list, ticket);
+            moments_budget_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(ticket, mom_shift, budget);
+            moments_chase_wide_kernel<<<dim3(4096), dim3(256), 0, ctx->stream>>>(def_list, ticket, n, mom_shift, LF, 1u << 16, uidx, ulf, ucap, ticket);
+        } else {
+            u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+            collect_unvisited_wide_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(LF, marks, n, uidx, ulf, ucap, ticket + 1);
+        }
         HIPC(hipGetLastError());
         return BWTS_OK;
     };
@@ -501,6 +624,7 @@ static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
     const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
     const u64 kc = ctx->h_small[SMI_COUNTERS + 2];
+    if (moments && ctx->h_small[SMI_COUNTERS + 11]) { *need_marks = true; return BWTS_OK; }     // too many unreached elements for the moments: the byte map
     ctx->tm.unvisited = nu;
     ctx->unv_hint = (size_t)nu;
     if (nu > n || kc == 0 || kc > s_all) return BWTS_E_INTERNAL;
