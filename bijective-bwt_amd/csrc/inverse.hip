@@ -15,6 +15,7 @@
 #include "scan_templ.h"
 
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 #define LF_THREADS 256
@@ -174,12 +175,15 @@ __device__ __forceinline__ u32 symbol_of(const u64 *Ctab, u32 y)
 #define MARK_SENTINEL 1
 #define MARK_BYTEMAP 2
 #define MARK_MOMENTS 3
-//   3  moments     -- nothing is written per step: the workgroup keeps, per range of 2^shift indices (at most MOM_BUCKETS ranges),
-//                     how many it visited, the sum of their offsets and the sum of their squares (three LDS atomics).  A range that
-//                     misses one or two indices names them by arithmetic; a range that misses more is searched element by element
+//   3  moments     -- nothing is written per step: the workgroup keeps, per residue class of the index mod MOM_BUCKETS, how many
+//                     indices it visited, the sum of their quotients and the sum of the squares (three LDS atomics).  A class that
+//                     misses one or two indices names them by arithmetic; a class that misses more is searched element by element
 //                     (moments_chase_kernel: an element is unreached iff its own chase returns to it before it meets a splitter).
+//                     (Classes by the high bits -- ranges -- were the first form: the few dozen unreached elements of a text are the
+//                     rotations of its last, small Lyndon factors and sit in a handful of ranges, a dozen to each.)
 //                     The micro-benchmark puts the log at 7 % of the walk, and its scan at 1.4 ms (tools/micro/walk_steps.hip).
-#define MOM_BUCKETS 1024
+#define MOM_LOG2 10
+#define MOM_BUCKETS (1u << MOM_LOG2)
 template <int MARK, int SBW = 16 /* registers of recorded symbols per store: 16 = 64-byte blocks, 4 = 16-byte ones (BWTS_WALK_SYMS=16) */>
 __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, u8 *__restrict__ marks, u32 *__restrict__ idxlog, u64 s, u64 node_cap, int g, u32 slot,
                                                           const u64 *__restrict__ Cg, u8 *__restrict__ seg,
@@ -270,8 +274,8 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
             }
         }
         if (MARK == MARK_MOMENTS && have) {
-            const u32 b = x >> mom_shift;
-            const unsigned long long o = x & ((1u << mom_shift) - 1u);
+            const u32 b = x & (MOM_BUCKETS - 1u);                           // classes by the low bits: the unreached elements of real inputs cluster in rank
+            const unsigned long long o = x >> MOM_LOG2;
             atomicAdd(&mcnt[b], 1u); atomicAdd(&msum[b], o); atomicAdd(&msq[b], o * o);
         }
         if (have) {
@@ -699,9 +703,8 @@ __global__ __launch_bounds__(MOM_BUCKETS) void moments_solve_kernel(const unsign
                                                                     unsigned long long *__restrict__ counters)
 {
     const u64 b = threadIdx.x;
-    const u64 lo = b << shift;
-    if (lo >= n) return;
-    const u64 size = n - lo < (1ull << shift) ? n - lo : (1ull << shift);
+    if (b >= n) return;
+    const u64 size = (n - b + MOM_BUCKETS - 1) >> MOM_LOG2;                  // indices x < n with x mod MOM_BUCKETS = b: x = o * MOM_BUCKETS + b, o < size
     const u64 cnt = mom[b];
     if (cnt > size) { atomicAdd(&counters[11], 1ull); return; }
     const u64 d = size - cnt;
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(MOM_BUCKETS) void moments_solve_kernel(const unsign
     if (d == 1) {
         if (A >= size || A * A != B) { atomicAdd(&counters[11], 1ull); return; }
         const unsigned long long at = atomicAdd(&counters[1], 1ull);
-        if (at < ucap) { const u32 x = (u32)(lo + A); uidx[at] = x; ulf[at] = LF[x]; }
+        if (at < ucap) { const u32 x = (u32)((A << MOM_LOG2) | b); uidx[at] = x; ulf[at] = LF[x]; }
     } else if (d == 2) {
         const u64 D = 2 * B - A * A;                                         // (o1 - o2)^2
         u64 r = (u64)sqrt((double)D);
@@ -725,17 +728,17 @@ __global__ __launch_bounds__(MOM_BUCKETS) void moments_solve_kernel(const unsign
         const u64 o1 = (A - r) / 2, o2 = (A + r) / 2;
         if (r * r != D || r == 0 || ((A - r) & 1) || o2 >= size || o1 * o1 + o2 * o2 != B) { atomicAdd(&counters[11], 1ull); return; }
         const unsigned long long at = atomicAdd(&counters[1], 2ull);
-        if (at < ucap) { const u32 x = (u32)(lo + o1); uidx[at] = x; ulf[at] = LF[x]; }
-        if (at + 1 < ucap) { const u32 x = (u32)(lo + o2); uidx[at + 1] = x; ulf[at + 1] = LF[x]; }
+        if (at < ucap) { const u32 x = (u32)((o1 << MOM_LOG2) | b); uidx[at] = x; ulf[at] = LF[x]; }
+        if (at + 1 < ucap) { const u32 x = (u32)((o2 << MOM_LOG2) | b); uidx[at + 1] = x; ulf[at + 1] = LF[x]; }
     } else {
         const unsigned long long at = atomicAdd(&counters[10], 1ull);
         def_list[at] = (u32)b;
     }
 }
 // (own launch, after the one above: all ranges are listed) more elements to search than the budget allows: fall back to the log instead
-__global__ void moments_budget_kernel(unsigned long long *__restrict__ counters, int shift, u64 budget)
+__global__ void moments_budget_kernel(unsigned long long *__restrict__ counters, u64 per_class, u64 budget)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && (counters[10] << shift) > budget) { counters[11] += 1; counters[10] = 0; }
+    if (threadIdx.x == 0 && blockIdx.x == 0 && counters[10] * per_class > budget) { counters[11] += 1; counters[10] = 0; }
 }
 // every element of the listed ranges follows LF until it stands on a splitter (a walk came through it: reached) or on itself
 // (its cycle holds no splitter: unreached).  `cap` steps without either: counters[11] (the caller falls back to the log).
@@ -743,13 +746,15 @@ __global__ __launch_bounds__(256) void moments_chase_kernel(const u32 *__restric
                                                             const u32 *__restrict__ LF, u32 cap, u32 *__restrict__ uidx, u32 *__restrict__ ulf, u64 ucap,
                                                             unsigned long long *__restrict__ counters)
 {
-    const u64 ranges = counters_in[10];
-    const u64 per = (1ull << shift) / 256 ? (1ull << shift) / 256 : 1;      // 256-element pieces per range
+    const u64 classes = counters_in[10];
+    const u64 members = (n + MOM_BUCKETS - 1) >> MOM_LOG2;                   // quotients a class may hold
+    const u64 per = (members + 255) / 256;                                   // 256-element pieces per class
     const u32 gmask = (1u << g) - 1u;
-    for (u64 w = blockIdx.x; w < ranges * per; w += gridDim.x) {
-        const u64 x0 = ((u64)def_list[w / per] << shift) + (w % per) * 256 + threadIdx.x;
+    (void)shift;
+    for (u64 w = blockIdx.x; w < classes * per; w += gridDim.x) {
+        const u64 x0 = (((w % per) * 256 + threadIdx.x) << MOM_LOG2) | (u64)def_list[w / per];
         bool un = false;
-        if (x0 < n && (threadIdx.x < (1u << shift) || shift >= 8)) {
+        if (x0 < n) {
             if ((x0 & gmask) != 0) {                                         // a splitter is where a walk starts: reached
                 u32 y = LF[x0], steps = 0;
                 for (;;) {
@@ -915,8 +920,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     *ambiguous = false;
     if (need_log) *need_log = false;
     const bool moments = mark == MARK_MOMENTS;
-    int mom_shift = 0;
-    while (((n + (1ull << mom_shift) - 1) >> mom_shift) > MOM_BUCKETS) mom_shift++;
+    const int mom_shift = MOM_LOG2;             // (classes by low bits: the parameter only documents the class count to the kernels)
     const u64 G = 1ull << g;
     const u64 s = (n + G - 1) / G;
     const u64 tiles = (n + LF_TILE - 1) / LF_TILE;
@@ -1046,9 +1050,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
         if (moments) {
             if (!first_time) HIPC(hipMemsetAsync(ticket + 10, 0, 2 * sizeof(u64), ctx->stream));
-            const u64 budget = (4ull << 20) > (1ull << mom_shift) ? (4ull << 20) : (1ull << mom_shift);        // elements the search may look at
+            const u64 per_class = (n + MOM_BUCKETS - 1) >> MOM_LOG2;
+            const u64 budget = (4ull << 20) > per_class ? (4ull << 20) : per_class;        // elements the search may look at (at least one class)
             moments_solve_kernel<<<dim3(1), dim3(MOM_BUCKETS), 0, ctx->stream>>>(mom, n, mom_shift, LF, uidx, ulf, ucap, def_list, ticket);
-            moments_budget_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(ticket, mom_shift, budget);
+            moments_budget_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(ticket, (n + MOM_BUCKETS - 1) >> MOM_LOG2, budget);
             moments_chase_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(def_list, ticket, n, mom_shift, g, LF, 1u << 16, uidx, ulf, ucap, ticket);
         } else if (mark == MARK_LOG) {
             const int bm_bytes = (int)((1u << IDX_RANGE_LOG2) / 8);
@@ -1084,6 +1089,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
     const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
     const u64 nu2 = ctx->h_small[SMI_COUNTERS + 6];
+    static const bool inv_trace = [] { const char *e = getenv("BWTS_INV_TRACE"); return e && atoi(e) == 1; }();
+    if (inv_trace && moments)
+        fprintf(stderr, "[inverse] moments: shift %d, unreached found %llu, ranges searched %llu, fallback flag %llu\n", mom_shift,
+                (unsigned long long)ctx->h_small[SMI_COUNTERS + 1], (unsigned long long)ctx->h_small[SMI_COUNTERS + 10], (unsigned long long)ctx->h_small[SMI_COUNTERS + 11]);
     if (moments && ctx->h_small[SMI_COUNTERS + 11]) {          // the ranges' moments do not name the unreached elements: the index log does
         if (need_log) *need_log = true;
         return BWTS_OK;

@@ -73,7 +73,8 @@ struct WiNode { u32 nxt, len; u64 mn; u32 off, pad; };
 // walk_record_kernel of the main path with 64-bit elements and byte-map marks (see there for the scheme)
 // MOM: no byte map; the unreached elements come from per-range moments (inverse.hip, MARK_MOMENTS) over WMOM_BUCKETS ranges kept in
 // dynamic LDS (80 KB: two workgroups per CU) -- the random byte write per step was what held this walk at half the main path's rate
-#define WMOM_BUCKETS 4096
+#define WMOM_LOG2 12
+#define WMOM_BUCKETS (1u << WMOM_LOG2)
 template <bool MOM>
 __global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__restrict__ LF, u8 *__restrict__ marks, u64 s, u64 node_cap, u32 slot,
                                                                const u64 *__restrict__ Cg, u8 *__restrict__ seg, WiNode *__restrict__ nodes,
@@ -124,8 +125,8 @@ __global__ __launch_bounds__(256) void walk_record_wide_kernel(const u64 *__rest
         if (have) {
             const u64 y = LF[x];
             if (MOM) {
-                const u32 b = (u32)(x >> mom_shift);
-                const unsigned long long o = x & ((1ull << mom_shift) - 1ull);
+                const u32 b = (u32)x & (WMOM_BUCKETS - 1u);                  // residue classes (see inverse.hip, MARK_MOMENTS)
+                const unsigned long long o = x >> WMOM_LOG2;
                 atomicAdd(&mcnt[b], 1u); atomicAdd(&msum[b], o); atomicAdd(&msq[b], o * o);
             } else marks[x] = 1;
             {
@@ -182,9 +183,8 @@ __global__ __launch_bounds__(1024) void moments_solve_wide_kernel(const unsigned
                                                                   unsigned long long *__restrict__ counters)
 {
     const u64 b = (u64)blockIdx.x * 1024 + threadIdx.x;
-    const u64 lo = b << shift;
-    if (b >= WMOM_BUCKETS || lo >= n) return;
-    const u64 size = n - lo < (1ull << shift) ? n - lo : (1ull << shift);
+    if (b >= WMOM_BUCKETS || b >= n) return;
+    const u64 size = (n - b + WMOM_BUCKETS - 1) >> WMOM_LOG2;
     const u64 cnt = mom[b];
     if (cnt > size) { atomicAdd(&counters[11], 1ull); return; }
     const u64 d = size - cnt;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(1024) void moments_solve_wide_kernel(const unsigned
     if (d == 1) {
         if (A >= size || A * A != B) { atomicAdd(&counters[11], 1ull); return; }
         const unsigned long long at = atomicAdd(&counters[1], 1ull);
-        if (at < ucap) { const u64 x = lo + A; uidx[at] = x; ulf[at] = LF[x]; }
+        if (at < ucap) { const u64 x = (A << WMOM_LOG2) | b; uidx[at] = x; ulf[at] = LF[x]; }
     } else if (d == 2) {
         const u64 D = 2 * B - A * A;
         u64 r = (u64)sqrt((double)D);
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(1024) void moments_solve_wide_kernel(const unsigned
         const u64 o1 = (A - r) / 2, o2 = (A + r) / 2;
         if (A >= 2 * size || r * r != D || r == 0 || ((A - r) & 1) || o2 >= size || o1 * o1 + o2 * o2 != B) { atomicAdd(&counters[11], 1ull); return; }
         const unsigned long long at = atomicAdd(&counters[1], 2ull);
-        if (at < ucap) { const u64 x = lo + o1; uidx[at] = x; ulf[at] = LF[x]; }
-        if (at + 1 < ucap) { const u64 x = lo + o2; uidx[at + 1] = x; ulf[at + 1] = LF[x]; }
+        if (at < ucap) { const u64 x = (o1 << WMOM_LOG2) | b; uidx[at] = x; ulf[at] = LF[x]; }
+        if (at + 1 < ucap) { const u64 x = (o2 << WMOM_LOG2) | b; uidx[at + 1] = x; ulf[at + 1] = LF[x]; }
     } else {
         const unsigned long long at = atomicAdd(&counters[10], 1ull);
         def_list[at] = (u32)b;
@@ -217,13 +217,15 @@ __global__ __launch_bounds__(256) void moments_chase_wide_kernel(const u32 *__re
                                                                  const u64 *__restrict__ LF, u32 cap, u64 *__restrict__ uidx, u64 *__restrict__ ulf, u64 ucap,
                                                                  unsigned long long *__restrict__ counters)
 {
-    const u64 ranges = counters_in[10];
-    const u64 per = (1ull << shift) / 256 ? (1ull << shift) / 256 : 1;
+    const u64 classes = counters_in[10];
+    const u64 members = (n + WMOM_BUCKETS - 1) >> WMOM_LOG2;
+    const u64 per = (members + 255) / 256;
     const u64 gmask = (1ull << WI_G_LOG2) - 1ull;
-    for (u64 w = blockIdx.x; w < ranges * per; w += gridDim.x) {
-        const u64 x0 = ((u64)def_list[w / per] << shift) + (w % per) * 256 + threadIdx.x;
+    (void)shift;
+    for (u64 w = blockIdx.x; w < classes * per; w += gridDim.x) {
+        const u64 x0 = (((w % per) * 256 + threadIdx.x) << WMOM_LOG2) | (u64)def_list[w / per];
         bool un = false;
-        if (x0 < n && (threadIdx.x < (1u << (shift < 8 ? shift : 8)) || shift >= 8)) {
+        if (x0 < n) {
             if ((x0 & gmask) != 0) {
                 u64 y = LF[x0];
                 u32 steps = 0;
@@ -487,8 +489,7 @@ static int inverse_wide_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out,
 {
     *need_marks = false;
     if (n > (1ull << 36)) return BWTS_E_RANGE;
-    int mom_shift = 0;
-    while (((n + (1ull << mom_shift) - 1) >> mom_shift) > WMOM_BUCKETS) mom_shift++;
+    const int mom_shift = WMOM_LOG2;
     const u64 G = 1ull << WI_G_LOG2;
     const u64 s = (n + G - 1) / G;
     const u32 slot = (u32)(4 * G);
@@ -596,9 +597,10 @@ static int inverse_wide_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out,
         SpanGuard sg(ctx, BWTS_K_OTHER, n, n);
         if (moments) {
             HIPC(hipMemsetAsync(ticket + 10, 0, 2 * sizeof(u64), ctx->stream));
-            const u64 budget = (8ull << 20) > (1ull << mom_shift) ? (8ull << 20) : (1ull << mom_shift);        // elements the search may look at
+            const u64 per_class = (n + WMOM_BUCKETS - 1) >> WMOM_LOG2;
+            const u64 budget = (8ull << 20) > per_class ? (8ull << 20) : per_class;        // elements the search may look at (at least one class)
             moments_solve_wide_kernel<<<dim3(WMOM_BUCKETS / 1024), dim3(1024), 0, ctx->stream>>>(mom, n, mom_shift, LF, uidx, ulf, ucap, def_list, ticket);
-            moments_budget_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(ticket, mom_shift, budget);
+            moments_budget_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(ticket, per_class, budget);
             moments_chase_wide_kernel<<<dim3(4096), dim3(256), 0, ctx->stream>>>(def_list, ticket, n, mom_shift, LF, 1u << 16, uidx, ulf, ucap, ticket);
         } else {
             u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
