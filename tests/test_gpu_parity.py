@@ -762,6 +762,8 @@ def test_text_1GiB_properties(ctx):
     {"BWTS_DENSE": "legacy"},                         # later rounds with many ties: list in SA order, radix-sorted, instead of the group-local rounds
     {"BWTS_DENSE": "legacy", "BWTS_SEGSORT": "0"},                            # later rounds: radix sort of the whole tied list instead of sorting small groups in place
     {"BWTS_RX_SMALL": "0"},                           # small sorts through the multi-launch passes instead of the one-workgroup kernel
+    {"BWTS_RX_FUSED_SCAN": "0"},                      # column scan of the tile table in five launches instead of the fused kernel
+    {"BWTS_WALK_SYMS": "16", "BWTS_INV_MARK": "log"},   # inverse walk with 16-byte symbol stores (a variant of the index-log walk)
     {"BWTS_K0DIR": "0"},                              # sparse key builder: plain binary searches, no directories                      # dense rank array by two plain scatters instead of the binned one
     {"BWTS_INV_MARK": "log"},                         # inverse logs every visited index (the fallback of the per-range moments)
     {"BWTS_INV_MARK": "sentinel"},                    # inverse marks visited entries in place instead of logging them
