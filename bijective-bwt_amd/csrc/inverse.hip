@@ -175,15 +175,16 @@ __device__ __forceinline__ u32 symbol_of(const u64 *Ctab, u32 y)
 #define MARK_SENTINEL 1
 #define MARK_BYTEMAP 2
 #define MARK_MOMENTS 3
-//   3  moments     -- nothing is written per step: the workgroup keeps, per residue class of the index mod MOM_BUCKETS, how many
+//   3  moments     -- nothing is written per step: the workgroup keeps, per residue class of the index mod 2^10 (2^12 above n = 2^30), how many
 //                     indices it visited, the sum of their quotients and the sum of the squares (three LDS atomics).  A class that
 //                     misses one or two indices names them by arithmetic; a class that misses more is searched element by element
 //                     (moments_chase_kernel: an element is unreached iff its own chase returns to it before it meets a splitter).
 //                     (Classes by the high bits -- ranges -- were the first form: the few dozen unreached elements of a text are the
 //                     rotations of its last, small Lyndon factors and sit in a handful of ranges, a dozen to each.)
 //                     The micro-benchmark puts the log at 7 % of the walk, and its scan at 1.4 ms (tools/micro/walk_steps.hip).
-#define MOM_LOG2 10
-#define MOM_BUCKETS (1u << MOM_LOG2)
+#define MOM_LOG2_SMALL 10                    // classes: 2^10 up to n = 2^30 (20 KB of LDS), 2^12 above (80 KB: a class stays at 2^20 elements)
+#define MOM_LOG2_LARGE 12
+#define MOM_MAX_BUCKETS (1u << MOM_LOG2_LARGE)
 template <int MARK, int SBW = 16 /* registers of recorded symbols per store: 16 = 64-byte blocks, 4 = 16-byte ones (BWTS_WALK_SYMS=16) */>
 __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, u8 *__restrict__ marks, u32 *__restrict__ idxlog, u64 s, u64 node_cap, int g, u32 slot,
                                                           const u64 *__restrict__ Cg, u8 *__restrict__ seg,
@@ -193,12 +194,14 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                                                           unsigned long long *__restrict__ overflow,
                                                           unsigned long long *__restrict__ chunk_ctr, u32 *__restrict__ chunk_fill, u64 log_chunks,
                                                           u32 nbuckets, u32 *__restrict__ bucket_seen,
-                                                          int mom_shift = 0, unsigned long long *__restrict__ mom = nullptr /* [3][MOM_BUCKETS]: counts, sums, sums of squares */)
+                                                          int mom_shift = 0, unsigned long long *__restrict__ mom = nullptr /* [3][2^mom_shift]: counts, sums, sums of squares */)
 {
     __shared__ u64 Ctab[257];
-    __shared__ u32 mcnt[MARK == MARK_MOMENTS ? MOM_BUCKETS : 1];
-    __shared__ unsigned long long msum[MARK == MARK_MOMENTS ? MOM_BUCKETS : 1], msq[MARK == MARK_MOMENTS ? MOM_BUCKETS : 1];
-    if (MARK == MARK_MOMENTS) for (u32 b = threadIdx.x; b < MOM_BUCKETS; b += 256) { mcnt[b] = 0; msum[b] = 0; msq[b] = 0; }
+    extern __shared__ __attribute__((aligned(16))) unsigned long long walk_mom_sm[];     // MARK_MOMENTS: 2^mom_shift sums, sums of squares, counts
+    const u32 mom_classes = MARK == MARK_MOMENTS ? 1u << mom_shift : 0u;
+    unsigned long long *msum = walk_mom_sm, *msq = walk_mom_sm + mom_classes;
+    u32 *mcnt = (u32 *)(walk_mom_sm + 2 * mom_classes);
+    if (MARK == MARK_MOMENTS) for (u32 b = threadIdx.x; b < mom_classes; b += 256) { mcnt[b] = 0; msum[b] = 0; msq[b] = 0; }
     // MARK_LOG: how many indices of each 2^IDX_RANGE_LOG2-range this workgroup visited.  A range that ends up with all of
     // its indices counted holds nothing unvisited, and its log entries need not be looked at again.
     __shared__ u32 bseen[MARK == MARK_LOG ? IDX_MAX_BUCKETS : 1];
@@ -274,8 +277,8 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
             }
         }
         if (MARK == MARK_MOMENTS && have) {
-            const u32 b = x & (MOM_BUCKETS - 1u);                           // classes by the low bits: the unreached elements of real inputs cluster in rank
-            const unsigned long long o = x >> MOM_LOG2;
+            const u32 b = x & (mom_classes - 1u);                           // classes by the low bits: the unreached elements of real inputs cluster in rank
+            const unsigned long long o = x >> mom_shift;
             atomicAdd(&mcnt[b], 1u); atomicAdd(&msum[b], o); atomicAdd(&msq[b], o * o);
         }
         if (have) {
@@ -329,9 +332,9 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
     }
     if (MARK == MARK_MOMENTS) {
         __syncthreads();
-        for (u32 b = threadIdx.x; b < MOM_BUCKETS; b += 256) {
+        for (u32 b = threadIdx.x; b < mom_classes; b += 256) {
             const u32 c = mcnt[b];
-            if (c) { atomicAdd(&mom[b], (unsigned long long)c); atomicAdd(&mom[MOM_BUCKETS + b], msum[b]); atomicAdd(&mom[2 * MOM_BUCKETS + b], msq[b]); }
+            if (c) { atomicAdd(&mom[b], (unsigned long long)c); atomicAdd(&mom[mom_classes + b], msum[b]); atomicAdd(&mom[2 * mom_classes + b], msq[b]); }
         }
     }
 #ifdef WALK_PROFILE
@@ -698,13 +701,14 @@ __global__ __launch_bounds__(256) void lr2_distribute_kernel(const uint4 *__rest
 // One thread per range.  missing = size - count; one missing index: its offset is (sum of all offsets) - (sum seen); two: their sum A and
 // the sum of their squares B give (o1 - o2)^2 = 2 B - A^2.  More: the range goes onto the list for moments_chase_kernel.
 // counters: [1] unreached elements (as for the other marks), [10] listed ranges, [11] the arithmetic did not come out (fall back to the log)
-__global__ __launch_bounds__(MOM_BUCKETS) void moments_solve_kernel(const unsigned long long *__restrict__ mom, u64 n, int shift, const u32 *__restrict__ LF,
+__global__ __launch_bounds__(1024) void moments_solve_kernel(const unsigned long long *__restrict__ mom, u64 n, int shift /* log2 of the class count */, const u32 *__restrict__ LF,
                                                                     u32 *__restrict__ uidx, u32 *__restrict__ ulf, u64 ucap, u32 *__restrict__ def_list,
                                                                     unsigned long long *__restrict__ counters)
 {
-    const u64 b = threadIdx.x;
-    if (b >= n) return;
-    const u64 size = (n - b + MOM_BUCKETS - 1) >> MOM_LOG2;                  // indices x < n with x mod MOM_BUCKETS = b: x = o * MOM_BUCKETS + b, o < size
+    const u64 b = (u64)blockIdx.x * 1024 + threadIdx.x;
+    const u64 classes = 1ull << shift;
+    if (b >= classes || b >= n) return;
+    const u64 size = (n - b + classes - 1) >> shift;                         // indices x < n with x mod classes = b: x = o * classes + b, o < size
     const u64 cnt = mom[b];
     if (cnt > size) { atomicAdd(&counters[11], 1ull); return; }
     const u64 d = size - cnt;
@@ -715,11 +719,11 @@ __global__ __launch_bounds__(MOM_BUCKETS) void moments_solve_kernel(const unsign
     u64 f[3] = {a3, b3, c3};
     { int two = 0, three = 0; for (int i = 0; i < 3; i++) { if (!two && f[i] % 2 == 0) { f[i] /= 2; two = 1; } } for (int i = 0; i < 3; i++) { if (!three && f[i] % 3 == 0) { f[i] /= 3; three = 1; } } }
     const u64 qall = f[0] * f[1] * f[2];
-    const u64 A = sall - mom[MOM_BUCKETS + b], B = qall - mom[2 * MOM_BUCKETS + b];
+    const u64 A = sall - mom[classes + b], B = qall - mom[2 * classes + b];
     if (d == 1) {
         if (A >= size || A * A != B) { atomicAdd(&counters[11], 1ull); return; }
         const unsigned long long at = atomicAdd(&counters[1], 1ull);
-        if (at < ucap) { const u32 x = (u32)((A << MOM_LOG2) | b); uidx[at] = x; ulf[at] = LF[x]; }
+        if (at < ucap) { const u32 x = (u32)((A << shift) | b); uidx[at] = x; ulf[at] = LF[x]; }
     } else if (d == 2) {
         const u64 D = 2 * B - A * A;                                         // (o1 - o2)^2
         u64 r = (u64)sqrt((double)D);
@@ -728,8 +732,8 @@ __global__ __launch_bounds__(MOM_BUCKETS) void moments_solve_kernel(const unsign
         const u64 o1 = (A - r) / 2, o2 = (A + r) / 2;
         if (r * r != D || r == 0 || ((A - r) & 1) || o2 >= size || o1 * o1 + o2 * o2 != B) { atomicAdd(&counters[11], 1ull); return; }
         const unsigned long long at = atomicAdd(&counters[1], 2ull);
-        if (at < ucap) { const u32 x = (u32)((o1 << MOM_LOG2) | b); uidx[at] = x; ulf[at] = LF[x]; }
-        if (at + 1 < ucap) { const u32 x = (u32)((o2 << MOM_LOG2) | b); uidx[at + 1] = x; ulf[at + 1] = LF[x]; }
+        if (at < ucap) { const u32 x = (u32)((o1 << shift) | b); uidx[at] = x; ulf[at] = LF[x]; }
+        if (at + 1 < ucap) { const u32 x = (u32)((o2 << shift) | b); uidx[at + 1] = x; ulf[at + 1] = LF[x]; }
     } else {
         const unsigned long long at = atomicAdd(&counters[10], 1ull);
         def_list[at] = (u32)b;
@@ -747,12 +751,11 @@ __global__ __launch_bounds__(256) void moments_chase_kernel(const u32 *__restric
                                                             unsigned long long *__restrict__ counters)
 {
     const u64 classes = counters_in[10];
-    const u64 members = (n + MOM_BUCKETS - 1) >> MOM_LOG2;                   // quotients a class may hold
+    const u64 members = (n + (1ull << shift) - 1) >> shift;                  // quotients a class may hold
     const u64 per = (members + 255) / 256;                                   // 256-element pieces per class
     const u32 gmask = (1u << g) - 1u;
-    (void)shift;
     for (u64 w = blockIdx.x; w < classes * per; w += gridDim.x) {
-        const u64 x0 = (((w % per) * 256 + threadIdx.x) << MOM_LOG2) | (u64)def_list[w / per];
+        const u64 x0 = (((w % per) * 256 + threadIdx.x) << shift) | (u64)def_list[w / per];
         bool un = false;
         if (x0 < n) {
             if ((x0 & gmask) != 0) {                                         // a splitter is where a walk starts: reached
@@ -920,7 +923,8 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     *ambiguous = false;
     if (need_log) *need_log = false;
     const bool moments = mark == MARK_MOMENTS;
-    const int mom_shift = MOM_LOG2;             // (classes by low bits: the parameter only documents the class count to the kernels)
+    const int mom_shift = n > (1ull << 30) ? MOM_LOG2_LARGE : MOM_LOG2_SMALL;       // log2 of the number of residue classes
+    const u64 mom_classes = 1ull << mom_shift;
     const u64 G = 1ull << g;
     const u64 s = (n + G - 1) / G;
     const u64 tiles = (n + LF_TILE - 1) / LF_TILE;
@@ -939,8 +943,8 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
                                     (mark == MARK_LOG ? align_up(log_chunks * IDX_CHUNK * 4, 256) + align_up(log_chunks * 4, 256) + align_up(n * 4 + (4ull << IDX_RANGE_LOG2), 256) + (1 << 20) : 0) +
                                     (1 << 17)));
     u32 *LF = arena_array<u32>(ctx, n);
-    unsigned long long *mom = moments ? (unsigned long long *)arena_array<u64>(ctx, 3 * MOM_BUCKETS) : nullptr;
-    u32 *def_list = moments ? arena_array<u32>(ctx, MOM_BUCKETS) : nullptr;
+    unsigned long long *mom = moments ? (unsigned long long *)arena_array<u64>(ctx, 3 * MOM_MAX_BUCKETS) : nullptr;
+    u32 *def_list = moments ? arena_array<u32>(ctx, MOM_MAX_BUCKETS) : nullptr;
     if (moments && (!mom || !def_list)) return BWTS_E_NOMEM;
     u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
     void *scan_temp = arena_alloc(ctx, scan_temp_bytes(n));
@@ -995,15 +999,16 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         HIPC(hipMemsetAsync(chunk_fill, 0, log_chunks * sizeof(u32), ctx->stream));
         HIPC(hipMemsetAsync(bucket_seen, 0, IDX_MAX_BUCKETS * sizeof(u32), ctx->stream));
     }
-    if (moments) HIPC(hipMemsetAsync(mom, 0, 3 * MOM_BUCKETS * sizeof(u64), ctx->stream));
+    if (moments) HIPC(hipMemsetAsync(mom, 0, 3 * mom_classes * sizeof(u64), ctx->stream));
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 6 * n);
         static const bool syms16 = [] { const char *e = getenv("BWTS_WALK_SYMS"); return e && atoi(e) == 16; }();      // 16-byte symbol stores (A/B against the 64-byte ones)
-        if (moments)
-            walk_record_kernel<MARK_MOMENTS><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
+        if (moments) {
+            BWTS_TRY(ensure_dyn_lds(ctx, (const void *)walk_record_kernel<MARK_MOMENTS>, (size_t)MOM_MAX_BUCKETS * 20));
+            walk_record_kernel<MARK_MOMENTS><<<dim3(wblocks), dim3(256), (size_t)mom_classes * 20, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
                                                                                           ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen,
                                                                                           mom_shift, mom);
-        else if (mark == MARK_BYTEMAP)
+        } else if (mark == MARK_BYTEMAP)
             walk_record_kernel<MARK_BYTEMAP><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
                                                                                           ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         else if (mark == MARK_SENTINEL)
@@ -1050,10 +1055,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
         if (moments) {
             if (!first_time) HIPC(hipMemsetAsync(ticket + 10, 0, 2 * sizeof(u64), ctx->stream));
-            const u64 per_class = (n + MOM_BUCKETS - 1) >> MOM_LOG2;
+            const u64 per_class = (n + mom_classes - 1) >> mom_shift;
             const u64 budget = (4ull << 20) > per_class ? (4ull << 20) : per_class;        // elements the search may look at (at least one class)
-            moments_solve_kernel<<<dim3(1), dim3(MOM_BUCKETS), 0, ctx->stream>>>(mom, n, mom_shift, LF, uidx, ulf, ucap, def_list, ticket);
-            moments_budget_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(ticket, (n + MOM_BUCKETS - 1) >> MOM_LOG2, budget);
+            moments_solve_kernel<<<dim3((unsigned)((mom_classes + 1023) / 1024)), dim3(1024), 0, ctx->stream>>>(mom, n, mom_shift, LF, uidx, ulf, ucap, def_list, ticket);
+            moments_budget_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(ticket, per_class, budget);
             moments_chase_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(def_list, ticket, n, mom_shift, g, LF, 1u << 16, uidx, ulf, ucap, ticket);
         } else if (mark == MARK_LOG) {
             const int bm_bytes = (int)((1u << IDX_RANGE_LOG2) / 8);
