@@ -1,3 +1,3 @@
 # GPU session r02ce: device memory per input byte (contexts of their own, device-resident buffers not counted)
-python tools/diag/mem.py
+python tools/device_memory.py
 exit 0
