@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libbwts_hip.so")
 KINDS = {"uniform256": 0, "zipf": 1, "dna": 2, "text": 3}
 
 K_NAMES = ["histogram", "keybuild", "radix_hist", "radix_scan", "radix_scatter", "rerank", "lyndon", "emit",
-           "lf_build", "walk", "listrank", "walk_emit", "other", "radix_scatter_main"]
+           "lf_build", "walk", "listrank", "walk_emit", "other", "radix_scatter_main", "round"]
 K_COUNT = len(K_NAMES)
 MAX_ROUND_STATS = 40
 

@@ -8,6 +8,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+void bwts_trace_error(const char *file, int line, int rc)
+{
+    static const bool on = [] { const char *e = getenv("BWTS_TRACE_ERRORS"); return e && e[0] == '1'; }();
+    if (on) fprintf(stderr, "[bwts] %s:%d: rc %d\n", file, line, rc);
+}
+
 // ------------------------------------------------------------------------------------
 // arenas
 // ------------------------------------------------------------------------------------
@@ -543,7 +549,7 @@ extern "C" int bwts_last_timings(bwts_ctx *ctx, bwts_timings *t)
 extern "C" const char *bwts_kernel_class_name(int k)
 {
     static const char *names[BWTS_K_COUNT] = {"histogram", "keybuild", "radix_hist", "radix_scan", "radix_scatter", "rerank",
-                                              "lyndon", "emit", "lf_build", "walk", "listrank", "walk_emit", "other", "radix_scatter_main"};
+                                              "lyndon", "emit", "lf_build", "walk", "listrank", "walk_emit", "other", "radix_scatter_main", "round"};
     return (k >= 0 && k < BWTS_K_COUNT) ? names[k] : "?";
 }
 

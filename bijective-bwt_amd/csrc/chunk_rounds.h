@@ -1,0 +1,687 @@
+// chunk_rounds.h -- the rounds after round 0 when many elements are tied, third form: CHUNKS.  Included by forward.hip.
+//
+// dense_rounds() (forward.hip) runs a round as three n-sized launches -- the round kernel leaves (position, head, state) for
+// every list element, a count sweep reads the states, the compaction reads all three again -- with two host round trips, and a
+// workgroup looks at DG_SPAN list slots to decide DG_OWN of them (a quarter of its loads are halo).  Here the list is cut ONCE
+// into chunks at group boundaries, and a chunk belongs to one workgroup in every round:
+//   * groups never straddle chunks, so a round needs no halo and no global compaction: the workgroup walks its chunk in tiles of
+//     CH_TILE slots cut at group starts, orders every group in LDS exactly like dense_round_kernel, and writes the members that
+//     stay tied back IN PLACE, compacted to the front of the chunk (the write cursor never passes the read cursor);
+//   * the rank array is only read by the round kernel: the new ranks of the elements whose rank changed go to a per-chunk move
+//     list, which chunk_apply_moves_kernel applies when the round's gathers are all done (a round's keys must come from one version
+//     of the ranks);
+//   * the grid is one workgroup per chunk in every round and the sizes live on the device, so the host has nothing to read back
+//     between rounds except "is anything left / did anything split": once no larger group is left it enqueues two rounds per sync.
+// Groups of more than CH_CAP members never enter a chunk.  The one-off order by smallest position puts them behind all the others;
+// they form the BIG LIST, which goes through the sort-based round (gather, two radix sorts, regroup -- the larger-group path of
+// dense_rounds on a dense list), and whatever falls to CH_CAP members or fewer leaves the big list as new chunks appended behind
+// the existing ones.  Groups only ever split, so an element is appended at most once and the chunk store never outgrows the list.
+#pragma once
+
+#define CH_THREADS 512
+#define CH_ITEMS   4
+#define CH_TILE    (CH_THREADS * CH_ITEMS)
+#define CH_CAP     DG_CAP
+#define CH_WORDS   (CH_TILE / 64)
+#define CH_WORDS_BACK ((CH_CAP + 63) / 64)
+#ifndef CH_MIN_WAVES
+#define CH_MIN_WAVES 8
+#endif
+#define CH_MIN_LIST 65536ull            // shorter lists keep the tile form (dense_rounds)
+#define CH_SLOTS   4                    // result slots of rounds in flight
+#define CH_SLOT_WORDS 8
+#define SM_CHSLOT  (SM_DGCNT + 16)      // CH_SLOTS x CH_SLOT_WORDS words inside the dense rounds' counter block
+enum { CHS_SPLIT = 0, CHS_ERR = 1, CHS_TOTAL = 2, CHS_EXIT = 3, CHS_STAY = 4 };
+static_assert(CH_CAP * 4 <= CH_TILE, "a tile must hold several whole groups");
+static_assert(16 + CH_SLOTS * CH_SLOT_WORDS <= DG_CNT_BIG + DG_CNT_SPREAD, "result slots live in the dense rounds' counter block");
+
+// chunk c = list slots [cstart[c], cstart[c] + ccount[c]); the region up to cstart[c + 1] (or the store's tail) is its own
+template <bool CYCLIC, int NKEYS>
+__global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u32 *idx, u32 *head, const u32 *__restrict__ cstart, u32 *__restrict__ ccount,
+                                                                 u64 *__restrict__ mv, u32 *__restrict__ mvcount,
+                                                                 const u32 *__restrict__ rank, u64 n, u64 h,
+                                                                 const u32 *__restrict__ fstart, u64 k, PrevSym prev, u8 *__restrict__ out,
+                                                                 unsigned long long *__restrict__ result)
+{
+    __shared__ u32 hd[CH_TILE];              // group heads of the tile
+    __shared__ u32 key[CH_TILE];             // successor ranks
+    __shared__ u64 key23[NKEYS == 3 ? CH_TILE : 1];
+    __shared__ u64 startm[CH_WORDS];         // bit = a group starts at this slot
+    __shared__ u64 keepm[CH_WORDS];          // bit = the element sorted into this slot stays tied
+    __shared__ u32 kpre[CH_WORDS];
+    __shared__ u32 fs[DG_FS_LDS];
+    __shared__ u32 s_surv, s_nmv, s_split, s_err;
+    const int tid0 = threadIdx.x;
+    const u32 c = blockIdx.x;
+    const u64 base = (u64)(u32)__builtin_amdgcn_readfirstlane((int)cstart[c]);
+    const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)ccount[c]);
+    if (cnt == 0) { if (tid0 == 0) mvcount[c] = 0; return; }
+    const bool fs_lds = CYCLIC && k <= DG_FS_LDS;
+    if (fs_lds) for (u32 i = tid0; i < k; i += CH_THREADS) fs[i] = fstart[i];
+    if (tid0 == 0) { s_nmv = 0; s_split = 0; s_err = 0; }
+    u32 rp = 0, wp = 0;                      // read / write cursors inside the chunk (uniform)
+    while (rp < cnt) {
+        // (an opaque copy of the thread id per iteration: left to itself the compiler hoists every address it can form from
+        // tid out of the loop and keeps ~80 registers of them alive through the whole body -- 132 VGPRs instead of 48)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const u32 len = cnt - rp < CH_TILE ? cnt - rp : (u32)CH_TILE;
+        const bool final_tile = rp + len == cnt;
+        u32 myh[CH_ITEMS], myp[CH_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) {
+            const u32 sl = (u32)j * CH_THREADS + tid;
+            myh[j] = sl < len ? head[base + rp + sl] : 0u;
+            myp[j] = sl < len ? idx[base + rp + sl] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) hd[j * CH_THREADS + tid] = myh[j];
+        if (tid < CH_WORDS) keepm[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) {
+            const u32 sl = (u32)j * CH_THREADS + tid;
+            // slot 0 starts a group by construction (chunks and tiles are cut at group starts); slots past the end count as starts
+            const bool st = sl >= len || sl == 0 || myh[j] != hd[sl - 1];
+            const u64 m = __ballot(st);
+            if (lane == 0) startm[sl >> 6] = m;
+        }
+        __syncthreads();
+        // the group the tile's last start opens may go on in the next tile: it is left for that one
+        u32 plen = len;
+        if (!final_tile) {
+            int w = CH_WORDS - 1;
+            u64 m = startm[w];
+            while (m == 0 && w > 0) { w--; m = startm[w]; }
+            plen = (u32)w * 64u + 63u - (u32)__clzll((long long)m);
+        }
+        plen = (u32)__builtin_amdgcn_readfirstlane((int)plen);        // uniform: keep it (and the cursors) in scalar registers
+        if (plen == 0) { if (tid == 0) s_err = 1; break; }          // a group of a whole tile: larger than CH_CAP, cannot be here
+        u32 gs[CH_ITEMS], sz[CH_ITEMS];
+        bool act[CH_ITEMS];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) {
+            const u32 sl = (u32)j * CH_THREADS + tid;
+            act[j] = sl < plen;
+            gs[j] = 0; sz[j] = 0;
+            if (!act[j]) continue;
+            const u32 w = sl >> 6, b = sl & 63u;
+            const u64 cur = startm[w];
+            const u64 below = b == 63 ? cur : cur & ((2ull << b) - 1ull);
+            int g = -1;
+            if (below) g = (int)(w * 64 + 63 - (u32)__clzll((long long)below));
+            else {
+#pragma unroll
+                for (u32 d = 1; d <= CH_WORDS_BACK; d++)
+                    if (g < 0 && w >= d) { const u64 pm = startm[w - d]; if (pm) g = (int)((w - d) * 64 + 63 - (u32)__clzll((long long)pm)); }
+            }
+            const u64 above = b == 63 ? 0ull : cur >> (b + 1);
+            int e = -1;
+            if (above) e = (int)(sl + 1 + (u32)__ffsll((unsigned long long)above) - 1);
+            else {
+#pragma unroll
+                for (u32 d = 1; d <= CH_WORDS_BACK; d++)
+                    if (e < 0 && w + d < CH_WORDS) { const u64 nm = startm[w + d]; if (nm) e = (int)((w + d) * 64 + (u32)__ffsll((unsigned long long)nm) - 1); }
+            }
+            if (e < 0 || (u32)e > plen) e = (int)plen;
+            if (g < 0 || e - g > CH_CAP) {
+                bad = true; act[j] = false;
+                if (atomicCAS(&result[5], 0ull, 1ull + c) == 0ull) {       // first failure: where (read by the host under BWTS_ROUND_TRACE)
+                    result[6] = ((u64)(u32)g << 32) | (u32)e;
+                    result[7] = ((u64)plen << 48) | ((u64)len << 32) | ((u64)rp << 16) | sl;
+                }
+                continue;
+            }
+            gs[j] = (u32)g; sz[j] = (u32)(e - g);
+        }
+        if (bad) s_err = 1;
+        // successor ranks
+        u32 my_key[CH_ITEMS];
+        u64 my_key23[NKEYS == 3 ? CH_ITEMS : 1];
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) {
+            my_key[j] = 0;
+            if (NKEYS == 3) my_key23[NKEYS == 3 ? j : 0] = 0;
+            if (!act[j]) continue;
+            const u64 p = myp[j];
+            if (CYCLIC) {
+                u64 lo = 0, hi = k - 1;
+                if (fs_lds) { while (lo < hi) { const u64 mid = (lo + hi + 1) >> 1; if ((u64)fs[mid] <= p) lo = mid; else hi = mid - 1; } }
+                else lo = factor_of(fstart, k, p);
+                const u64 s0 = fs_lds ? fs[lo] : fstart[lo];
+                const u64 e1 = lo + 1 < k ? (u64)(fs_lds ? fs[lo + 1] : fstart[lo + 1]) : n;
+                my_key[j] = rank[cyclic_successor(p, s0, e1 - s0, h)];
+                if (NKEYS == 3) {
+                    const u32 r2 = rank[cyclic_successor(p, s0, e1 - s0, 2 * h)], r3 = rank[cyclic_successor(p, s0, e1 - s0, 3 * h)];
+                    my_key23[NKEYS == 3 ? j : 0] = ((u64)r2 << 32) | r3;
+                }
+            } else {
+                const u64 q = p + h;
+                my_key[j] = q < n ? rank[q] + 1u : 0u;
+                if (NKEYS == 3) {
+                    const u64 q2 = p + 2 * h, q3 = p + 3 * h;
+                    const u32 r2 = q2 < n ? rank[q2] + 1u : 0u, r3 = q3 < n ? rank[q3] + 1u : 0u;
+                    my_key23[NKEYS == 3 ? j : 0] = ((u64)r2 << 32) | r3;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++)
+            if (act[j]) {
+                key[j * CH_THREADS + tid] = my_key[j];
+                if (NKEYS == 3) key23[NKEYS == 3 ? j * CH_THREADS + tid : 0] = my_key23[NKEYS == 3 ? j : 0];
+            }
+        __syncthreads();
+        // order inside the group by counting (as dense_round_kernel)
+        u32 dst[CH_ITEMS], newhead[CH_ITEMS];
+        bool alone[CH_ITEMS], moved[CH_ITEMS];
+        u32 split_here = 0;
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) {
+            const u32 sl = (u32)j * CH_THREADS + tid;
+            dst[j] = sl; newhead[j] = 0; alone[j] = false; moved[j] = false;
+            if (!act[j]) continue;
+            const u32 g0 = gs[j], gsz = sz[j], mine = key[sl];
+            u32 less = 0, eq = 0, eq_before = 0;
+            if (NKEYS == 3) {
+                const u64 mine23 = key23[NKEYS == 3 ? sl : 0];
+                u32 m = 0;
+                for (; m + 4 <= gsz; m += 4) {
+                    u32 ko[4]; u64 ko23[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { ko[q] = key[g0 + m + q]; ko23[q] = key23[NKEYS == 3 ? g0 + m + q : 0]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const bool same = ko[q] == mine && ko23[q] == mine23;
+                        less += (ko[q] < mine || (ko[q] == mine && ko23[q] < mine23)) ? 1u : 0u;
+                        eq += same ? 1u : 0u;
+                        eq_before += (same && g0 + m + q < sl) ? 1u : 0u;
+                    }
+                }
+                for (; m < gsz; m++) {
+                    const u32 ko = key[g0 + m];
+                    const u64 ko23 = key23[NKEYS == 3 ? g0 + m : 0];
+                    const bool same = ko == mine && ko23 == mine23;
+                    less += (ko < mine || (ko == mine && ko23 < mine23)) ? 1u : 0u;
+                    eq += same ? 1u : 0u;
+                    eq_before += (same && g0 + m < sl) ? 1u : 0u;
+                }
+            } else {
+                for (u32 m = 0; m < gsz; m++) {
+                    const u32 ko = key[g0 + m];
+                    less += ko < mine ? 1u : 0u;
+                    eq += ko == mine ? 1u : 0u;
+                    eq_before += (ko == mine && g0 + m < sl) ? 1u : 0u;
+                }
+            }
+            dst[j] = g0 + less + eq_before;
+            newhead[j] = hd[sl] + less;
+            alone[j] = eq == 1;
+            moved[j] = less != 0;
+            split_here |= eq < gsz ? 1u : 0u;
+        }
+        u32 pv[CH_ITEMS];
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) pv[j] = (out && act[j] && alone[j]) ? (u32)prev(myp[j]) : 0u;
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++)
+            if (act[j] && !alone[j]) atomicOr((unsigned long long *)&keepm[dst[j] >> 6], 1ull << (dst[j] & 63u));
+        // new ranks: to the chunk's move list (any order)
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) {
+            const bool mvd = act[j] && moved[j];
+            const u64 mm = __ballot(mvd);
+            if (mm) {
+                const int leader = __ffsll((unsigned long long)mm) - 1;
+                u32 b0 = 0;
+                if (lane == leader) b0 = atomicAdd(&s_nmv, (u32)__popcll(mm));
+                b0 = shfl_t(b0, leader);
+                if (mvd) mv[base + b0 + (u32)__popcll(mm & lanemask_lt())] = ((u64)newhead[j] << 32) | (u64)myp[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++)
+            if (out && act[j] && alone[j]) out[newhead[j]] = (u8)pv[j];
+        if (split_here) s_split = 1;
+        __syncthreads();
+        if (tid < 64) {
+            const u32 cpop = tid < CH_WORDS ? (u32)__popcll(keepm[tid < CH_WORDS ? tid : 0]) : 0u;
+            const u32 inc = wave_scan_inclusive(cpop, OpAdd());
+            if (tid < CH_WORDS) kpre[tid] = inc - cpop;
+            if (tid == CH_WORDS - 1) s_surv = inc;
+        }
+        __syncthreads();
+        // the members that stay, in sorted order, to the front of the chunk: wp + survivors <= rp + plen, and every load of this
+        // tile is behind the barriers above, so nothing unread is overwritten
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++)
+            if (act[j] && !alone[j]) {
+                const u32 w = dst[j] >> 6, b = dst[j] & 63u;
+                const u64 lowbits = keepm[w] & ((1ull << b) - 1ull);
+                const u32 o = wp + kpre[w] + (u32)__popcll(lowbits);
+                idx[base + o] = myp[j];
+                head[base + o] = newhead[j];
+            }
+        wp += (u32)__builtin_amdgcn_readfirstlane((int)s_surv);
+        rp += plen;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid0 == 0) {
+        ccount[c] = wp;
+        mvcount[c] = s_nmv;
+        if (s_split && __hip_atomic_load(&result[CHS_SPLIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(&result[CHS_SPLIT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_err) __hip_atomic_store(&result[CHS_ERR], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// rank[position] = new rank for everything a round moved; runs when every gather of the round is done
+__global__ __launch_bounds__(256) void chunk_apply_moves_kernel(const u64 *__restrict__ mv, const u32 *__restrict__ cstart, const u32 *__restrict__ mvcount,
+                                                                u32 *__restrict__ rank)
+{
+    const u32 c = blockIdx.x;
+    const u32 m = mvcount[c];
+    const u64 base = cstart[c];
+    for (u32 i = threadIdx.x; i < m; i += 256) { const u64 e = mv[base + i]; rank[(u32)e] = (u32)(e >> 32); }
+}
+
+// elements still tied over all chunks (one workgroup: at most a few 10^4 chunks)
+__global__ __launch_bounds__(1024) void chunk_total_kernel(const u32 *__restrict__ ccount, u32 nchunks, unsigned long long *__restrict__ result)
+{
+    __shared__ u64 sm[16];
+    u64 s = 0;
+    for (u32 i = threadIdx.x; i < nchunks; i += 1024) s += ccount[i];
+    s = wave_scan_inclusive(s, OpAdd());
+    if (lane_id() == 63) sm[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { u64 t = 0; for (int w = 0; w < 16; w++) t += sm[w]; result[CHS_TOTAL] = t; }
+}
+
+// chunks c0 .. c0 + nch over list slots [lo, hi): chunk i nominally starts at lo + i * S, actually at the first group start at
+// or after that (groups here have at most CH_CAP members, so the walk is short)
+__global__ __launch_bounds__(256) void chunk_init_kernel(const u32 *__restrict__ head, u64 lo, u64 hi, u32 S, u32 c0, u32 nch,
+                                                         u32 *__restrict__ cstart, u32 *__restrict__ ccount, u32 *__restrict__ mvcount)
+{
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nch) return;
+    u64 s = lo + (u64)i * S;
+    if (s > hi) s = hi;
+    while (s > lo && s < hi && head[s] == head[s - 1]) s++;
+    u64 e = hi;
+    if (i + 1 < nch) {
+        e = lo + (u64)(i + 1) * S;
+        if (e > hi) e = hi;
+        while (e > lo && e < hi && head[e] == head[e - 1]) e++;
+    }
+    cstart[c0 + i] = (u32)s;
+    ccount[c0 + i] = (u32)(e - s);
+    mvcount[c0 + i] = 0;
+}
+
+// what is left when no group splits any more (equal infinite words): the members take their group's slots in list order
+__global__ __launch_bounds__(256) void chunk_rest_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, const u32 *__restrict__ cstart,
+                                                         const u32 *__restrict__ ccount, PrevSym prev, u8 *__restrict__ out, u32 *__restrict__ SA)
+{
+    const u32 c = blockIdx.x;
+    const u64 base = cstart[c];
+    const u32 cnt = ccount[c];
+    for (u32 i = threadIdx.x; i < cnt; i += 256) {
+        const u32 hh = head[base + i];
+        u32 o = 0;
+        while (o < i && head[base + i - o - 1] == hh) o++;
+        const u32 slot = hh + o, p = idx[base + i];
+        if (out) out[slot] = prev(p);
+        if (SA) SA[slot] = p;
+    }
+}
+
+// first list slot of the larger groups: the one-off order puts them behind everything else (sort key >= n)
+__global__ void chunk_find_big_kernel(const u64 *__restrict__ keys, u64 a, int sort_bits, u64 first_big_key, unsigned long long *__restrict__ result)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const u64 mask = sort_bits >= 64 ? ~0ull : ((1ull << sort_bits) - 1ull);
+    u64 lo = 0, hi = a;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if ((keys[mid] & mask) < first_big_key) lo = mid + 1; else hi = mid;
+    }
+    *result = lo;
+}
+
+// ---- the big list ---------------------------------------------------------------------------------------------------------
+struct BlIn {
+    const u32 *head;
+    __device__ __forceinline__ u32 operator()(u64 j) const { return (j == 0 || head[j] != head[j - 1]) ? 1u : 0u; }
+};
+template <bool CYCLIC>
+struct BlOut {
+    const u32 *head; const u32 *idx; int rb; const u32 *rank; u64 n; u64 h; const u32 *fstart; u64 k;
+    u64 *bk; u32 *bv;
+    u64 *k23, *k23_sort; u32 *j_sort;        // quadrupled step (null otherwise): see DgBigOut
+    __device__ __forceinline__ void operator()(u64 j, u32 before) const
+    {
+        const u32 st = (j == 0 || head[j] != head[j - 1]) ? 1u : 0u;
+        const u64 ord = (u64)before + st - 1;
+        const u64 p = idx[j];
+        u64 r1, r2 = 0, r3 = 0;
+        if (CYCLIC) {
+            const u64 f = factor_of(fstart, k, p);
+            const u64 s0 = fstart[f], L = factor_end(fstart, k, n, f) - s0;
+            r1 = rank[cyclic_successor(p, s0, L, h)];
+            if (k23) { r2 = rank[cyclic_successor(p, s0, L, 2 * h)]; r3 = rank[cyclic_successor(p, s0, L, 3 * h)]; }
+        } else {
+            const u64 q = p + h;
+            r1 = q < n ? (u64)rank[q] + 1ull : 0ull;
+            if (k23) {
+                const u64 q2 = p + 2 * h, q3 = p + 3 * h;
+                r2 = q2 < n ? (u64)rank[q2] + 1ull : 0ull;
+                r3 = q3 < n ? (u64)rank[q3] + 1ull : 0ull;
+            }
+        }
+        bk[j] = (ord << rb) | r1;
+        bv[j] = (u32)p;
+        if (k23) { const u64 v = (r2 << rb) | r3; k23[j] = v; k23_sort[j] = v; j_sort[j] = (u32)j; }
+    }
+};
+// after the sorts: new heads, final bytes, new ranks (every gather of the round is done by now), in sorted order
+struct BlRegroupOut {
+    const u64 *bk; const u32 *bv; const u32 *oldhead; u64 m; int rb;
+    u32 *t_idx; u32 *t_head; u32 *rank; PrevSym prev; u8 *out; unsigned long long *result;
+    const u32 *src; const u64 *k23;
+    __device__ __forceinline__ void operator()(u64 j, u64 v) const       // inclusive (max, max) scan value, see DgRegroupIn
+    {
+        const u32 gidx = (u32)(v >> 32) - 1u, sidx = (u32)v - 1u;
+        const bool last_of_sub = j + 1 == m || bk[j + 1] != bk[j] || (k23 && k23[src[j + 1]] != k23[src[j]]);
+        const bool alone = sidx == (u32)j && last_of_sub;
+        const u32 newhead = oldhead[j] + (sidx - gidx);        // sorting keeps every group on its own slots, all holding its old head
+        const u32 p = src ? bv[src[j]] : bv[j];
+        t_idx[j] = p; t_head[j] = newhead;
+        if (sidx != gidx) rank[p] = newhead;
+        if (alone && out) out[newhead] = prev(p);
+        const u64 splitm = __ballot(sidx != gidx);
+        if (splitm && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1 &&
+            __hip_atomic_load(&result[CHS_SPLIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            __hip_atomic_store(&result[CHS_SPLIT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+// class of every element of the regrouped big list: 0 alone (finished), 1 in a group of 2 .. CH_CAP (leaves for a chunk), 2 stays
+__global__ __launch_bounds__(DG_THREADS) void bl_classify_kernel(const u32 *__restrict__ t_idx, const u32 *__restrict__ t_head, u64 m, u8 *__restrict__ cls)
+{
+    __shared__ u32 hd[DG_SPAN];
+    __shared__ u64 startm[DG_SPAN / 64];
+    const int tid = threadIdx.x;
+    const long long e0 = (long long)blockIdx.x * DG_OWN - DG_CAP;
+    DgSlots ds;
+    dg_detect(t_idx, t_head, m, e0, hd, startm, ds);
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        if (!ds.kind[j]) continue;
+        const u64 e = (u64)(e0 + j * DG_THREADS + tid);
+        cls[e] = (u8)(ds.kind[j] == 2 ? 2 : (ds.sz[j] >= 2 ? 1 : 0));
+    }
+}
+struct BlSplitIn {
+    const u8 *cls;
+    __device__ __forceinline__ u64 operator()(u64 i) const { const u32 c = cls[i]; return (u64)(c == 1 ? 1u : 0u) | ((u64)(c == 2 ? 1u : 0u) << 32); }
+};
+struct BlSplitOut {
+    const u8 *cls; const u32 *t_idx; const u32 *t_head; u64 m;
+    u32 *x_idx, *x_head;          // where the leaving elements go (the chunk store's tail)
+    u32 *s_idx, *s_head;          // the next big list
+    unsigned long long *result;
+    __device__ __forceinline__ void operator()(u64 i, u64 before) const
+    {
+        const u32 c = cls[i];
+        if (c == 1) { const u32 o = (u32)before; x_idx[o] = t_idx[i]; x_head[o] = t_head[i]; }
+        else if (c == 2) { const u32 o = (u32)(before >> 32); s_idx[o] = t_idx[i]; s_head[o] = t_head[i]; }
+        if (i + 1 == m) { result[CHS_EXIT] = (u64)(u32)before + (c == 1 ? 1u : 0u); result[CHS_STAY] = (before >> 32) + (c == 2 ? 1u : 0u); }
+    }
+};
+
+static u32 chunk_nominal_size(u64 a)
+{
+    // about 16 K chunks, between one and eight tiles each
+    u64 s = (a / 16384 + 1023) / 1024 * 1024;
+    if (s < CH_TILE) s = CH_TILE;
+    if (s > 8 * CH_TILE) s = 8 * CH_TILE;
+    return (u32)s;
+}
+
+// Same contract as dense_rounds().  *handled = false: this form does not apply (short list, no room) and nothing was changed.
+template <bool CYCLIC>
+static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, const u32 *d_fstart, u64 k, SortSpace &sp,
+                        ActiveList cur, u64 a0, u32 *SA, bool need_sa, u32 *rounds_io, bool *handled)
+{
+    *handled = false;
+    if (a0 > 0xffffffffull || a0 < CH_MIN_LIST) return BWTS_OK;
+    static const bool round_trace = [] { const char *e = getenv("BWTS_ROUND_TRACE"); return e && atoi(e) == 1; }();
+#define CH_TRY(call) do { const int rc__ = (call); if (rc__ != BWTS_OK) { if (round_trace) fprintf(stderr, "[chunks] line %d: rc %d\n", __LINE__, rc__); return rc__; } } while (0)
+#define CH_HIP(call) do { const hipError_t e__ = (call); if (e__ != hipSuccess) { ctx->last_hip = (int)e__; if (round_trace) fprintf(stderr, "[chunks] line %d: hip error %d\n", __LINE__, (int)e__); return BWTS_E_HIP; } } while (0)
+#define CH_FAIL(why) do { if (round_trace) fprintf(stderr, "[chunks] invariant: %s (round %u)\n", why, rounds); return BWTS_E_INTERNAL; } while (0)
+    const size_t e4 = align_up((size_t)a0 * 4, 256), e8 = align_up((size_t)a0 * 8, 256);
+    const u32 S = chunk_nominal_size(a0);
+    const u64 maxchunks = a0 / S + 1024;                 // every append adds at most one ragged chunk; rounds are capped at 80
+    const size_t ct4 = align_up((size_t)(maxchunks + 1) * 4, 256);
+    char *base = nullptr, *ob = nullptr;
+    int rc = aux_reserve(ctx, 2 * e4 + e8 + 3 * ct4, &base);
+    if (rc == BWTS_E_NOMEM) return BWTS_OK;
+    CH_TRY(rc);
+    rc = aux_reserve_slot(ctx, 1, 2 * e8 + 2 * e4, &ob);
+    if (rc == BWTS_E_NOMEM) return BWTS_OK;
+    CH_TRY(rc);
+    *handled = true;
+    u32 *st_idx = (u32 *)base, *st_head = (u32 *)(base + e4);
+    u64 *mv = (u64 *)(base + 2 * e4);
+    u32 *cstart = (u32 *)(base + 2 * e4 + e8), *ccount = (u32 *)(base + 2 * e4 + e8 + ct4), *mvcount = (u32 *)(base + 2 * e4 + e8 + 2 * ct4);
+    u64 *slots = ctx->d_small + SM_CHSLOT;
+    const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
+    PrevSym prev{sp.carry_src, d_T, n, d_fstart, k};
+    u8 *out = CYCLIC ? sp.carry_out : nullptr;
+    u32 rounds = *rounds_io;
+    // order key of a list element: (group head << kb) | smallest position of the group (n + head for the larger groups), kb a whole
+    // number of radix digits so that the sort on the low kb bits orders by that field alone
+    const int kb0 = bitlen_u64(2 * n - 1), kb = kb0 > 32 ? kb0 : (kb0 + 7) / 8 * 8, sort_bits = kb > 32 ? 32 : kb;
+
+    // ---- one-off order: groups by their smallest position, the larger groups behind all others (dg_minpos_kernel) ----
+    u64 a_small = 0;
+    {
+        SortPlan op;
+        op.keys[0] = (u64 *)ob; op.keys[1] = (u64 *)(ob + e8);
+        op.vals[0] = (u32 *)(ob + 2 * e8); op.vals[1] = (u32 *)(ob + 2 * e8 + e4);
+        op.tile_hist = sp.tile_hist; op.scan_temp = sp.scan_temp;
+        {
+            SpanGuard g(ctx, BWTS_K_RERANK, a0, 20 * a0);
+            dg_minpos_kernel<<<dim3((unsigned)((a0 + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a0, n, kb, op.keys[0], op.vals[0]);
+            CH_HIP(hipGetLastError());
+        }
+        int ores = 0;
+        CH_TRY(radix_sort_pairs(ctx, op, a0, sort_bits, &ores));
+        {
+            SpanGuard g(ctx, BWTS_K_RERANK, a0, 20 * a0);
+            dg_unpack_kernel<<<dim3((unsigned)((a0 + 255) / 256)), dim3(256), 0, ctx->stream>>>(op.keys[ores], op.vals[ores], a0, kb, st_idx, st_head);
+            chunk_find_big_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(op.keys[ores], a0, sort_bits, kb > 32 ? n >> (kb - 32) : n,
+                                                                        (unsigned long long *)(slots + CHS_TOTAL));
+            CH_HIP(hipGetLastError());
+        }
+        CH_TRY(read_small(ctx, SM_CHSLOT, CH_SLOT_WORDS));
+        a_small = ctx->h_small[SM_CHSLOT + CHS_TOTAL];
+        if (a_small > a0) CH_FAIL("boundary of the larger groups");
+    }
+    u64 m_big = a0 - a_small;
+    if (round_trace) fprintf(stderr, "[chunks] list %llu: in chunks %llu (nominal chunk %u), big list %llu\n", (unsigned long long)a0,
+                             (unsigned long long)a_small, S, (unsigned long long)m_big);
+
+    // ---- big list buffers (the order sort's block, free again) ----
+    const size_t m4 = align_up((size_t)m_big * 4, 256), m8 = align_up((size_t)m_big * 8, 256), m1 = align_up((size_t)m_big, 256);
+    static const bool step4_ok = [] { const char *e = getenv("BWTS_DENSE_STEP"); return !(e && atoi(e) == 2); }();
+    const int nk = step4_ok ? 3 : 1;
+    u32 *bl_idx[2] = {nullptr, nullptr}, *bl_head[2] = {nullptr, nullptr}, *t_idx = nullptr, *t_head = nullptr, *bv[2] = {nullptr, nullptr}, *sv1 = nullptr;
+    u64 *bk[2] = {nullptr, nullptr}, *k23 = nullptr, *sk1 = nullptr;
+    u8 *cls = nullptr;
+    int blc = 0;
+    if (m_big) {
+        char *bb = nullptr;
+        CH_TRY(aux_reserve_slot(ctx, 1, 4 * m8 + 9 * m4 + m1, &bb));
+        char *q = bb;
+        for (int i = 0; i < 2; i++) { bl_idx[i] = (u32 *)q; q += m4; bl_head[i] = (u32 *)q; q += m4; }
+        t_idx = (u32 *)q; q += m4; t_head = (u32 *)q; q += m4;
+        bv[0] = (u32 *)q; q += m4; bv[1] = (u32 *)q; q += m4; sv1 = (u32 *)q; q += m4;
+        bk[0] = (u64 *)q; q += m8; bk[1] = (u64 *)q; q += m8; k23 = (u64 *)q; q += m8; sk1 = (u64 *)q; q += m8;
+        cls = (u8 *)q;
+        CH_HIP(hipMemcpyAsync(bl_idx[0], st_idx + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+        CH_HIP(hipMemcpyAsync(bl_head[0], st_head + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // ---- chunks over the smaller groups ----
+    u32 nchunks = 0;
+    u64 tail = a_small;                     // the store behind it is free: chunks leaving the big list are appended there
+    if (a_small) {
+        nchunks = (u32)((a_small + S - 1) / S);
+        chunk_init_kernel<<<dim3((nchunks + 255) / 256), dim3(256), 0, ctx->stream>>>(st_head, 0, a_small, S, 0, nchunks, cstart, ccount, mvcount);
+        CH_HIP(hipGetLastError());
+    }
+
+    u64 h = (u64)al.hstep;
+    const int hshift = nk == 3 ? 2 : 1;
+    u64 a_chunks = a_small;                 // elements in chunks after the last evaluated round
+    bool finished = false, stable = false;
+    while (!finished) {
+        const int B = m_big ? 1 : 2;        // rounds per host round trip
+        CH_HIP(hipMemsetAsync(slots, 0, CH_SLOTS * CH_SLOT_WORDS * sizeof(u64), ctx->stream));
+        u64 hs[CH_SLOTS];
+        for (int b = 0; b < B; b++) {
+            unsigned long long *res = (unsigned long long *)(slots + b * CH_SLOT_WORDS);
+            hs[b] = h;
+            if (nchunks) {
+                SpanGuard g(ctx, BWTS_K_ROUND, a_chunks, 32 * a_chunks);
+                if (nk == 3)
+                    chunk_round_kernel<CYCLIC, 3><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, sp.rank, n, h,
+                                                                                                      d_fstart, k, prev, out, res);
+                else
+                    chunk_round_kernel<CYCLIC, 1><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, sp.rank, n, h,
+                                                                                                      d_fstart, k, prev, out, res);
+                CH_HIP(hipGetLastError());
+            }
+            if (m_big) {
+                // the big list's gathers read the same version of the ranks as the chunks': before the moves are applied
+                SpanGuard g(ctx, BWTS_K_RERANK, m_big, 30 * m_big);
+                BlIn fin{bl_head[blc]};
+                BlOut<CYCLIC> fout{bl_head[blc], bl_idx[blc], rb, sp.rank, n, h, d_fstart, k, bk[0], bv[0],
+                                   nk == 3 ? k23 : nullptr, nk == 3 ? bk[1] : nullptr, nk == 3 ? bv[1] : nullptr};
+                CH_TRY((device_scan<false, u32>(ctx, m_big, fin, fout, OpAdd(), 0u, sp.scan_temp)));
+            }
+            if (nchunks) {
+                SpanGuard g(ctx, BWTS_K_ROUND, 0, 0);
+                chunk_apply_moves_kernel<<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(mv, cstart, mvcount, sp.rank);
+                chunk_total_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ccount, nchunks, res);
+                CH_HIP(hipGetLastError());
+            }
+            if (m_big) {
+                const int big_bits = bitlen_u64(m_big / (CH_CAP + 1)) + rb;          // ordinals < m_big / (CH_CAP + 1)
+                if (big_bits > 64) return BWTS_E_RANGE;
+                SortPlan bp;
+                bp.tile_hist = sp.tile_hist; bp.scan_temp = sp.scan_temp;
+                int rbig = 0;
+                const u64 *sorted_k1 = nullptr;
+                const u32 *src = nullptr, *positions = nullptr;
+                if (nk == 3) {
+                    // LSD over two key words: stable sort by (rank at 2h, rank at 3h), then by (group ordinal, rank at h)
+                    bp.keys[0] = bk[1]; bp.keys[1] = sk1;
+                    bp.vals[0] = bv[1]; bp.vals[1] = sv1;
+                    int r1 = 0;
+                    CH_TRY(radix_sort_pairs(ctx, bp, m_big, 2 * rb, &r1));
+                    u64 *kin = bp.keys[r1], *kout = bp.keys[r1 ^ 1];
+                    u32 *vin = bp.vals[r1], *vout = bp.vals[r1 ^ 1];
+                    {
+                        SpanGuard g(ctx, BWTS_K_RERANK, m_big, 20 * m_big);
+                        dg_stage2_keys_kernel<<<dim3((unsigned)((m_big + 255) / 256)), dim3(256), 0, ctx->stream>>>(vin, bk[0], m_big, kin);
+                        CH_HIP(hipGetLastError());
+                    }
+                    bp.keys[0] = kin; bp.keys[1] = kout;
+                    bp.vals[0] = vin; bp.vals[1] = vout;
+                    CH_TRY(radix_sort_pairs(ctx, bp, m_big, big_bits, &rbig));
+                    sorted_k1 = bp.keys[rbig]; src = bp.vals[rbig]; positions = bv[0];
+                } else {
+                    bp.keys[0] = bk[0]; bp.keys[1] = bk[1];
+                    bp.vals[0] = bv[0]; bp.vals[1] = bv[1];
+                    CH_TRY(radix_sort_pairs(ctx, bp, m_big, big_bits, &rbig));
+                    sorted_k1 = bk[rbig]; positions = bv[rbig];
+                }
+                SpanGuard g(ctx, BWTS_K_RERANK, m_big, 60 * m_big);
+                DgRegroupIn rin{sorted_k1, m_big, rb, src, nk == 3 ? k23 : nullptr};
+                BlRegroupOut rout{sorted_k1, positions, bl_head[blc], m_big, rb, t_idx, t_head, sp.rank, prev, out, res, src, nk == 3 ? k23 : nullptr};
+                CH_TRY((device_scan<true, u64>(ctx, m_big, rin, rout, OpMax2(), (u64)0, sp.scan_temp)));
+                bl_classify_kernel<<<dim3((unsigned)((m_big + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(t_idx, t_head, m_big, cls);
+                CH_HIP(hipGetLastError());
+                BlSplitIn sin{cls};
+                BlSplitOut sout{cls, t_idx, t_head, m_big, st_idx + tail, st_head + tail, bl_idx[blc ^ 1], bl_head[blc ^ 1], res};
+                CH_TRY((device_scan<false, u64>(ctx, m_big, sin, sout, OpAdd(), (u64)0, sp.scan_temp)));
+            }
+            h = h > (1ull << 60) ? h : h << hshift;
+        }
+        CH_TRY(read_small(ctx, SM_CHSLOT, CH_SLOTS * CH_SLOT_WORDS));
+        for (int b = 0; b < B && !finished; b++) {
+            const u64 *r = ctx->h_small + SM_CHSLOT + b * CH_SLOT_WORDS;
+            rounds++;
+            if (r[CHS_ERR]) {
+                if (round_trace) fprintf(stderr, "[chunks] chunk %llu of %u: group [%d, %d) plen %llu len %llu rp %llu slot %llu\n", (unsigned long long)r[5] - 1, nchunks,
+                                         (int)(r[6] >> 32), (int)(u32)r[6], (unsigned long long)(r[7] >> 48), (unsigned long long)((r[7] >> 32) & 0xffff),
+                                         (unsigned long long)((r[7] >> 16) & 0xffff), (unsigned long long)(r[7] & 0xffff));
+                CH_FAIL("a chunk met a group larger than CH_CAP");
+            }
+            const u64 in_chunks = nchunks ? r[CHS_TOTAL] : 0;
+            u64 m_exit = 0, m_stay = 0;
+            if (m_big) {
+                m_exit = r[CHS_EXIT]; m_stay = r[CHS_STAY];
+                if (m_exit + m_stay > m_big || tail + m_exit > a0) CH_FAIL("big list split counts");
+            }
+            if (in_chunks > a_chunks) CH_FAIL("chunks grew");
+            if (round_trace) fprintf(stderr, "[chunks] round %u h %llu: chunks %llu -> %llu, big list %llu -> stays %llu, leaves %llu\n", rounds,
+                                     (unsigned long long)hs[b], (unsigned long long)a_chunks, (unsigned long long)in_chunks, (unsigned long long)m_big,
+                                     (unsigned long long)m_stay, (unsigned long long)m_exit);
+            if (m_exit) {
+                const u32 add = (u32)((m_exit + S - 1) / S);
+                if ((u64)nchunks + add > maxchunks) CH_FAIL("chunk table full");
+                chunk_init_kernel<<<dim3((add + 255) / 256), dim3(256), 0, ctx->stream>>>(st_head, tail, tail + m_exit, S, nchunks, add, cstart, ccount, mvcount);
+                CH_HIP(hipGetLastError());
+                nchunks += add;
+                tail += m_exit;
+            }
+            if (m_big) { blc ^= 1; m_big = m_stay; }
+            a_chunks = in_chunks + m_exit;
+            const u64 left = a_chunks + m_big;
+            if (CYCLIC && rounds - 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[rounds - 1] = left;
+            if (left == 0) { finished = true; break; }
+            // no group split: the partition is stable under doubling -- what is left are groups of equal infinite words
+            if (CYCLIC && r[CHS_SPLIT] == 0) { finished = true; stable = true; break; }
+            if (!CYCLIC && hs[b] >= n) CH_FAIL("suffixes still tied at h >= n");      // suffixes are distinct; cannot happen
+            if (rounds > 80) CH_FAIL("more than 80 rounds");
+        }
+    }
+    if (need_sa) {
+        SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
+        u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
+        sa_from_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.rank, n, SA);
+        CH_HIP(hipGetLastError());
+    }
+    if (stable) {
+        // (a round enqueued behind the stable one has split nothing either: the lists are what they were)
+        SpanGuard g(ctx, BWTS_K_EMIT, a_chunks + m_big, 10 * (a_chunks + m_big));
+        if (nchunks && a_chunks) {
+            chunk_rest_kernel<<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, prev, out, need_sa ? SA : nullptr);
+            CH_HIP(hipGetLastError());
+        }
+        if (m_big) {
+            DgRestIn rin{bl_head[blc]};
+            DgRestOut rout{bl_idx[blc], bl_head[blc], prev, out, need_sa ? SA : nullptr};
+            CH_TRY((device_scan<true, u32>(ctx, m_big, rin, rout, OpMax(), 0u, sp.scan_temp)));
+        }
+    }
+    *rounds_io = rounds;
+    return BWTS_OK;
+#undef CH_FAIL
+#undef CH_TRY
+#undef CH_HIP
+}

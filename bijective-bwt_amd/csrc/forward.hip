@@ -1947,7 +1947,7 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u64 act_start[DG_MAX_ACT + 1];
     for (int r = 0; r <= DG_MAX_ACT; r++) act_start[r] = 0;
     static const bool reorder_ok = [] { const char *e = getenv("BWTS_DENSE_ORDER"); return !(e && atoi(e) == 0); }();
-    const int kb = bitlen_u64(2 * n - 1);
+    const int kb0 = bitlen_u64(2 * n - 1), kb = kb0 > 32 ? kb0 : (kb0 + 7) / 8 * 8;      // (a whole number of digits: the sort then orders by the position field alone)
     if (reorder_ok && a >= (1ull << 16)) {
         // groups in the order of their smallest position (see dg_minpos_kernel); the sorted list lands in sets[0]
         char *ob = nullptr;
@@ -2163,6 +2163,8 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     return BWTS_OK;
 }
 
+#include "chunk_rounds.h"
+
 // Sorts all positions by their (cyclic | suffix) word.  sp.keys[0]/sp.vals[0] hold the round-0
 // keys and the identity on entry.  want_ranks: leave final ranks in sp.rank (ISA for the suffix sort).
 template <bool CYCLIC>
@@ -2355,7 +2357,11 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
                 // group-local rounds; SA is only rebuilt when someone reads it afterwards (suffix array requested, or the
                 // gather form of the emission)
                 const bool need_sa = !CYCLIC || !sp.carry_out;
-                BWTS_TRY((dense_rounds<CYCLIC>(ctx, d_T, n, al, d_fstart, k, sp, cur, a, SA, need_sa, &rounds)));
+                // chunks (chunk_rounds.h) unless BWTS_DENSE=tiles asks for the second form, the list is short or memory is
+                static const bool tiles_only = [] { const char *e = getenv("BWTS_DENSE"); return e && !strcmp(e, "tiles"); }();
+                bool handled = false;
+                if (!tiles_only) BWTS_TRY((chunk_rounds<CYCLIC>(ctx, d_T, n, al, d_fstart, k, sp, cur, a, SA, need_sa, &rounds, &handled)));
+                if (!handled) BWTS_TRY((dense_rounds<CYCLIC>(ctx, d_T, n, al, d_fstart, k, sp, cur, a, SA, need_sa, &rounds)));
                 sp.ties_emitted = CYCLIC && sp.carry_out;
                 *sa_out = SA;
                 *rounds_out = rounds;

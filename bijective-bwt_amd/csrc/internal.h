@@ -97,10 +97,12 @@ struct bwts_ctx {
         if (e__ != hipSuccess) { ctx->last_hip = (int)e__; return BWTS_E_HIP; } \
     } while (0)
 
+// BWTS_TRACE_ERRORS=1: every failing call on the way up prints its place (a debugging aid; costs nothing until something fails)
+void bwts_trace_error(const char *file, int line, int rc);
 #define BWTS_TRY(call)                   \
     do {                                 \
         int rc__ = (call);               \
-        if (rc__ != BWTS_OK) return rc__; \
+        if (rc__ != BWTS_OK) { bwts_trace_error(__FILE__, __LINE__, rc__); return rc__; } \
     } while (0)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -57,6 +57,8 @@ enum {
     BWTS_K_WALK_EMIT,       /* placement of the recorded segments into the text            */
     BWTS_K_OTHER,
     BWTS_K_RADIX_SCATTER_MAIN, /* subset of RADIX_SCATTER: passes 1.. of the n-sized round-0 sort (one kernel variant) */
+    BWTS_K_ROUND,           /* group-local round over the tied list, in chunks: gather successor ranks, order every group in LDS,
+                               compact in place, apply the new ranks (32 algorithmic bytes per list element and round)          */
     BWTS_K_COUNT
 };
 
