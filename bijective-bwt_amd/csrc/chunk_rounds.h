@@ -27,21 +27,28 @@
 #ifndef CH_MIN_WAVES
 #define CH_MIN_WAVES 8
 #endif
+#define CH_FS      256                  // factors whose data a workgroup keeps in LDS (natural data has a dozen or two)
 #define CH_MIN_LIST 65536ull            // shorter lists keep the tile form (dense_rounds)
 #define CH_SLOTS   4                    // result slots of rounds in flight
 #define CH_SLOT_WORDS 8
 #define SM_CHSLOT  (SM_DGCNT + 16)      // CH_SLOTS x CH_SLOT_WORDS words inside the dense rounds' counter block
 enum { CHS_SPLIT = 0, CHS_ERR = 1, CHS_TOTAL = 2, CHS_EXIT = 3, CHS_STAY = 4 };
 static_assert(CH_CAP * 4 <= CH_TILE, "a tile must hold several whole groups");
-static_assert(16 + CH_SLOTS * CH_SLOT_WORDS <= DG_CNT_BIG + DG_CNT_SPREAD, "result slots live in the dense rounds' counter block");
+static_assert(16 + CH_SLOTS * CH_SLOT_WORDS + 1 <= DG_CNT_BIG + DG_CNT_SPREAD, "result slots live in the dense rounds' counter block");
 
-// chunk c = list slots [cstart[c], cstart[c] + ccount[c]); the region up to cstart[c + 1] (or the store's tail) is its own
+// chunk c = list slots [cstart[c], cstart[c] + ccount[c]); the region up to cstart[c + 1] (or the store's tail) is its own.
+// The kernel is bound by its VALU instructions, not by memory (the first version needed ~750 per element: 1.9 TB/s of algorithmic
+// bytes), so everything per element is 32-bit arithmetic: positions are u32 (n <= 2^32; lengths are kept modulo 2^32, which the
+// wrap-around of the cyclic successor absorbs), the factor of a position is not searched for -- natural data has one factor that
+// holds most of the text: fbig = (its start, its length) and the step reduced modulo that length are wave-uniform, and only
+// positions outside it take the general 64-bit path -- and a slot's group extent comes from the wave's own __ballot word (which is
+// exactly the 64 slots of its lanes) plus two per-word neighbour values, not from a bit search over LDS per lane.
 template <bool CYCLIC, int NKEYS>
 __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u32 *idx, u32 *head, const u32 *__restrict__ cstart, u32 *__restrict__ ccount,
                                                                  u64 *__restrict__ mv, u32 *__restrict__ mvcount,
                                                                  const u32 *__restrict__ rank, u64 n, u64 h,
-                                                                 const u32 *__restrict__ fstart, u64 k, PrevSym prev, u8 *__restrict__ out,
-                                                                 unsigned long long *__restrict__ result)
+                                                                 const u32 *__restrict__ fstart, u64 k, const u64 *__restrict__ fbig,
+                                                                 PrevSym prev, u8 *__restrict__ out, unsigned long long *__restrict__ result)
 {
     __shared__ u32 hd[CH_TILE];              // group heads of the tile
     __shared__ u32 key[CH_TILE];             // successor ranks
@@ -49,23 +56,54 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
     __shared__ u64 startm[CH_WORDS];         // bit = a group starts at this slot
     __shared__ u64 keepm[CH_WORDS];          // bit = the element sorted into this slot stays tied
     __shared__ u32 kpre[CH_WORDS];
-    __shared__ u32 fs[DG_FS_LDS];
+    __shared__ u32 ftab[CYCLIC ? 5 * CH_FS : 1];        // per factor: start, length (mod 2^32), the steps modulo the length
     __shared__ u32 s_surv, s_nmv, s_split, s_err;
     const int tid0 = threadIdx.x;
     const u32 c = blockIdx.x;
     const u64 base = (u64)(u32)__builtin_amdgcn_readfirstlane((int)cstart[c]);
     const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)ccount[c]);
     if (cnt == 0) { if (tid0 == 0) mvcount[c] = 0; return; }
-    const bool fs_lds = CYCLIC && k <= DG_FS_LDS;
-    if (fs_lds) for (u32 i = tid0; i < k; i += CH_THREADS) fs[i] = fstart[i];
     if (tid0 == 0) { s_nmv = 0; s_split = 0; s_err = 0; }
+    // the step, wave-uniform.  CYCLIC: the longest factor [sB, sB + LB) (LB modulo 2^32: 0 = the whole 4 GiB) and the steps modulo
+    // its length; suffixes: p + j h < n  <=>  p < nhj
+    u32 sB = 0, LB = 0, hm1 = 0, hm2 = 0, hm3 = 0, nh1 = 0, nh2 = 0, nh3 = 0;
+    if (CYCLIC) {
+        const u64 fb = fbig[0];
+        sB = (u32)fb; LB = (u32)(fb >> 32);
+        const u64 L64 = LB ? (u64)LB : (1ull << 32);
+        hm1 = (u32)(h < L64 ? h : h % L64);
+        if (NKEYS == 3) { hm2 = (u32)(2 * h < L64 ? 2 * h : (2 * h) % L64); hm3 = (u32)(3 * h < L64 ? 3 * h : (3 * h) % L64); }
+    } else {
+        nh1 = h < n ? (u32)(n - h) : 0u;            // (h >= 1, so n - h fits)
+        if (NKEYS == 3) { nh2 = 2 * h < n ? (u32)(n - 2 * h) : 0u; nh3 = 3 * h < n ? (u32)(n - 3 * h) : 0u; }
+    }
+    const u32 h32 = (u32)h;
+    const bool f_lds = CYCLIC && k <= CH_FS;
+    if (f_lds) {
+        // (a division only for factors shorter than the step: the short ones at the text's end)
+        for (u32 f = tid0; f < (u32)k; f += CH_THREADS) {
+            const u64 s0 = fstart[f], L = (f + 1 < (u32)k ? (u64)fstart[f + 1] : n) - s0;
+            ftab[f] = (u32)s0; ftab[CH_FS + f] = (u32)L;
+            ftab[2 * CH_FS + f] = (u32)(h < L ? h : h % L);
+            ftab[3 * CH_FS + f] = NKEYS == 3 ? (u32)(2 * h < L ? 2 * h : (2 * h) % L) : 0u;
+            ftab[4 * CH_FS + f] = NKEYS == 3 ? (u32)(3 * h < L ? 3 * h : (3 * h) % L) : 0u;
+        }
+    }
+    const u32 k32 = (u32)k;
     u32 rp = 0, wp = 0;                      // read / write cursors inside the chunk (uniform)
+#ifdef CH_PROFILE
+    long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#define CH_MARK(i) do { const long long tn__ = clock64(); pt[i] += tn__ - tprev; tprev = tn__; } while (0)
+#else
+#define CH_MARK(i) do { } while (0)
+#endif
     while (rp < cnt) {
         // (an opaque copy of the thread id per iteration: left to itself the compiler hoists every address it can form from
         // tid out of the loop and keeps ~80 registers of them alive through the whole body -- 132 VGPRs instead of 48)
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63;
+        const u32 wv = (u32)__builtin_amdgcn_readfirstlane(tid >> 6);
         const u32 len = cnt - rp < CH_TILE ? cnt - rp : (u32)CH_TILE;
         const bool final_tile = rp + len == cnt;
         u32 myh[CH_ITEMS], myp[CH_ITEMS];
@@ -79,13 +117,75 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
         for (int j = 0; j < CH_ITEMS; j++) hd[j * CH_THREADS + tid] = myh[j];
         if (tid < CH_WORDS) keepm[tid] = 0;
         __syncthreads();
+        CH_MARK(0);
+        // successor ranks: they depend on the positions alone, so the gathers are issued now and fly while the group extents are
+        // worked out (slots of a group that is left for the next tile are gathered for nothing)
+        u32 my_key[CH_ITEMS];
+        u64 my_key23[NKEYS == 3 ? CH_ITEMS : 1];
+        u32 ppos[CH_ITEMS];                      // position of the previous symbol, T[cprev(p)] (mk_bwts_sa.c:172-188), while the factor is at hand
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) {
+            my_key[j] = 0; ppos[j] = 0;
+            if (NKEYS == 3) my_key23[NKEYS == 3 ? j : 0] = 0;
+            if ((u32)j * CH_THREADS + tid >= len) continue;
+            const u32 p = myp[j];
+            if (CYCLIC) {
+                const u32 d = p - sB;                  // (p < sB wraps to a value >= LB)
+                u32 q1, q2 = 0, q3 = 0;
+                if (LB == 0 || d < LB) {
+                    // inside the longest factor: offset + step, minus the length when the sum passes it (a carry out of 32 bits
+                    // passes it too; with LB = 0 the subtraction does nothing and the wrapped sum is already right)
+                    ppos[j] = d ? p - 1u : sB + LB - 1u;
+                    u32 o = d + hm1;
+                    o = (o < d || o >= LB) ? o - LB : o;
+                    q1 = sB + o;
+                    if (NKEYS == 3) {
+                        u32 o2 = d + hm2, o3 = d + hm3;
+                        o2 = (o2 < d || o2 >= LB) ? o2 - LB : o2;
+                        o3 = (o3 < d || o3 >= LB) ? o3 - LB : o3;
+                        q2 = sB + o2; q3 = sB + o3;
+                    }
+                } else if (f_lds) {
+                    // another factor: binary search over the starts in LDS, then the same 32-bit arithmetic with its own length and steps
+                    u32 lo = 0, hi = k32 - 1;
+                    while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (ftab[mid] <= p) lo = mid; else hi = mid - 1; }
+                    const u32 s0 = ftab[lo], L = ftab[CH_FS + lo], dd = p - s0;
+                    ppos[j] = dd ? p - 1u : s0 + L - 1u;
+                    u32 o = dd + ftab[2 * CH_FS + lo];
+                    o = (o < dd || o >= L) ? o - L : o;
+                    q1 = s0 + o;
+                    if (NKEYS == 3) {
+                        u32 o2 = dd + ftab[3 * CH_FS + lo], o3 = dd + ftab[4 * CH_FS + lo];
+                        o2 = (o2 < dd || o2 >= L) ? o2 - L : o2;
+                        o3 = (o3 < dd || o3 >= L) ? o3 - L : o3;
+                        q2 = s0 + o2; q3 = s0 + o3;
+                    }
+                } else {
+                    const u64 f = factor_of(fstart, k, (u64)p);
+                    const u64 s0 = fstart[f], e1 = factor_end(fstart, k, n, f);
+                    ppos[j] = p == s0 ? (u32)(e1 - 1) : p - 1u;
+                    q1 = (u32)cyclic_successor(p, s0, e1 - s0, h);
+                    if (NKEYS == 3) { q2 = (u32)cyclic_successor(p, s0, e1 - s0, 2 * h); q3 = (u32)cyclic_successor(p, s0, e1 - s0, 3 * h); }
+                }
+                my_key[j] = rank[q1];
+                if (NKEYS == 3) { const u32 r2 = rank[q2], r3 = rank[q3]; my_key23[NKEYS == 3 ? j : 0] = ((u64)r2 << 32) | r3; }
+            } else {
+                my_key[j] = p < nh1 ? rank[p + h32] + 1u : 0u;
+                if (NKEYS == 3) {
+                    const u32 r2 = p < nh2 ? rank[p + 2u * h32] + 1u : 0u, r3 = p < nh3 ? rank[p + 3u * h32] + 1u : 0u;
+                    my_key23[NKEYS == 3 ? j : 0] = ((u64)r2 << 32) | r3;
+                }
+            }
+        }
+        // group starts: the 64 slots of a wave's item j are exactly word j * 8 + wave of the tile
+        u64 stm[CH_ITEMS];
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++) {
             const u32 sl = (u32)j * CH_THREADS + tid;
             // slot 0 starts a group by construction (chunks and tiles are cut at group starts); slots past the end count as starts
             const bool st = sl >= len || sl == 0 || myh[j] != hd[sl - 1];
-            const u64 m = __ballot(st);
-            if (lane == 0) startm[sl >> 6] = m;
+            stm[j] = __ballot(st);
+            if (lane == 0) startm[(u32)j * (CH_THREADS / 64) + wv] = stm[j];
         }
         __syncthreads();
         // the group the tile's last start opens may go on in the next tile: it is left for that one
@@ -98,34 +198,32 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
         }
         plen = (u32)__builtin_amdgcn_readfirstlane((int)plen);        // uniform: keep it (and the cursors) in scalar registers
         if (plen == 0) { if (tid == 0) s_err = 1; break; }          // a group of a whole tile: larger than CH_CAP, cannot be here
+        // per word (lane l < CH_WORDS of every wave <-> word l): the last start before it, the first start behind it
+        int cin_l = -1, cout_l = -1;
+        if (lane < CH_WORDS) {
+#pragma unroll
+            for (int d = 1; d <= CH_WORDS_BACK; d++)
+                if (cin_l < 0 && lane >= d) { const u64 pm = startm[lane - d]; if (pm) cin_l = (lane - d) * 64 + 63 - __clzll((long long)pm); }
+#pragma unroll
+            for (int d = 1; d <= CH_WORDS_BACK; d++)
+                if (cout_l < 0 && lane + d < CH_WORDS) { const u64 nm = startm[lane + d]; if (nm) cout_l = (lane + d) * 64 + __ffsll((unsigned long long)nm) - 1; }
+        }
+        const u64 le = lane == 63 ? ~0ull : (2ull << lane) - 1ull;       // slots of the word at or below mine
         u32 gs[CH_ITEMS], sz[CH_ITEMS];
         bool act[CH_ITEMS];
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++) {
             const u32 sl = (u32)j * CH_THREADS + tid;
+            const u32 w = (u32)j * (CH_THREADS / 64) + wv;
             act[j] = sl < plen;
             gs[j] = 0; sz[j] = 0;
-            if (!act[j]) continue;
-            const u32 w = sl >> 6, b = sl & 63u;
-            const u64 cur = startm[w];
-            const u64 below = b == 63 ? cur : cur & ((2ull << b) - 1ull);
-            int g = -1;
-            if (below) g = (int)(w * 64 + 63 - (u32)__clzll((long long)below));
-            else {
-#pragma unroll
-                for (u32 d = 1; d <= CH_WORDS_BACK; d++)
-                    if (g < 0 && w >= d) { const u64 pm = startm[w - d]; if (pm) g = (int)((w - d) * 64 + 63 - (u32)__clzll((long long)pm)); }
-            }
-            const u64 above = b == 63 ? 0ull : cur >> (b + 1);
-            int e = -1;
-            if (above) e = (int)(sl + 1 + (u32)__ffsll((unsigned long long)above) - 1);
-            else {
-#pragma unroll
-                for (u32 d = 1; d <= CH_WORDS_BACK; d++)
-                    if (e < 0 && w + d < CH_WORDS) { const u64 nm = startm[w + d]; if (nm) e = (int)((w + d) * 64 + (u32)__ffsll((unsigned long long)nm) - 1); }
-            }
+            const int cin = __builtin_amdgcn_readlane(cin_l, (int)w), cout = __builtin_amdgcn_readlane(cout_l, (int)w);
+            const u64 below = stm[j] & le, above = stm[j] & ~le;
+            const int g = below ? (int)(w * 64u) + 63 - __clzll((long long)below) : cin;
+            int e = above ? (int)(w * 64u) + __ffsll((unsigned long long)above) - 1 : cout;
             if (e < 0 || (u32)e > plen) e = (int)plen;
+            if (!act[j]) continue;
             if (g < 0 || e - g > CH_CAP) {
                 bad = true; act[j] = false;
                 if (atomicCAS(&result[5], 0ull, 1ull + c) == 0ull) {       // first failure: where (read by the host under BWTS_ROUND_TRACE)
@@ -137,36 +235,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
             gs[j] = (u32)g; sz[j] = (u32)(e - g);
         }
         if (bad) s_err = 1;
-        // successor ranks
-        u32 my_key[CH_ITEMS];
-        u64 my_key23[NKEYS == 3 ? CH_ITEMS : 1];
-#pragma unroll
-        for (int j = 0; j < CH_ITEMS; j++) {
-            my_key[j] = 0;
-            if (NKEYS == 3) my_key23[NKEYS == 3 ? j : 0] = 0;
-            if (!act[j]) continue;
-            const u64 p = myp[j];
-            if (CYCLIC) {
-                u64 lo = 0, hi = k - 1;
-                if (fs_lds) { while (lo < hi) { const u64 mid = (lo + hi + 1) >> 1; if ((u64)fs[mid] <= p) lo = mid; else hi = mid - 1; } }
-                else lo = factor_of(fstart, k, p);
-                const u64 s0 = fs_lds ? fs[lo] : fstart[lo];
-                const u64 e1 = lo + 1 < k ? (u64)(fs_lds ? fs[lo + 1] : fstart[lo + 1]) : n;
-                my_key[j] = rank[cyclic_successor(p, s0, e1 - s0, h)];
-                if (NKEYS == 3) {
-                    const u32 r2 = rank[cyclic_successor(p, s0, e1 - s0, 2 * h)], r3 = rank[cyclic_successor(p, s0, e1 - s0, 3 * h)];
-                    my_key23[NKEYS == 3 ? j : 0] = ((u64)r2 << 32) | r3;
-                }
-            } else {
-                const u64 q = p + h;
-                my_key[j] = q < n ? rank[q] + 1u : 0u;
-                if (NKEYS == 3) {
-                    const u64 q2 = p + 2 * h, q3 = p + 3 * h;
-                    const u32 r2 = q2 < n ? rank[q2] + 1u : 0u, r3 = q3 < n ? rank[q3] + 1u : 0u;
-                    my_key23[NKEYS == 3 ? j : 0] = ((u64)r2 << 32) | r3;
-                }
-            }
-        }
+        CH_MARK(1);
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++)
             if (act[j]) {
@@ -174,6 +243,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
                 if (NKEYS == 3) key23[NKEYS == 3 ? j * CH_THREADS + tid : 0] = my_key23[NKEYS == 3 ? j : 0];
             }
         __syncthreads();
+        CH_MARK(2);
         // order inside the group by counting (as dense_round_kernel)
         u32 dst[CH_ITEMS], newhead[CH_ITEMS];
         bool alone[CH_ITEMS], moved[CH_ITEMS];
@@ -222,9 +292,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
             moved[j] = less != 0;
             split_here |= eq < gsz ? 1u : 0u;
         }
+        CH_MARK(3);
         u32 pv[CH_ITEMS];
 #pragma unroll
-        for (int j = 0; j < CH_ITEMS; j++) pv[j] = (out && act[j] && alone[j]) ? (u32)prev(myp[j]) : 0u;
+        for (int j = 0; j < CH_ITEMS; j++) pv[j] = (out && act[j] && alone[j]) ? (prev.P ? (u32)prev.P[myp[j]] : (u32)prev.T[ppos[j]]) : 0u;
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++)
             if (act[j] && !alone[j]) atomicOr((unsigned long long *)&keepm[dst[j] >> 6], 1ull << (dst[j] & 63u));
@@ -238,7 +309,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
                 u32 b0 = 0;
                 if (lane == leader) b0 = atomicAdd(&s_nmv, (u32)__popcll(mm));
                 b0 = shfl_t(b0, leader);
-                if (mvd) mv[base + b0 + (u32)__popcll(mm & lanemask_lt())] = ((u64)newhead[j] << 32) | (u64)myp[j];
+                if (mvd) mv[base + b0 + (u32)__popcll(mm & (le >> 1))] = ((u64)newhead[j] << 32) | (u64)myp[j];
             }
         }
 #pragma unroll
@@ -246,6 +317,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
             if (out && act[j] && alone[j]) out[newhead[j]] = (u8)pv[j];
         if (split_here) s_split = 1;
         __syncthreads();
+        CH_MARK(4);
         if (tid < 64) {
             const u32 cpop = tid < CH_WORDS ? (u32)__popcll(keepm[tid < CH_WORDS ? tid : 0]) : 0u;
             const u32 inc = wave_scan_inclusive(cpop, OpAdd());
@@ -267,6 +339,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
         wp += (u32)__builtin_amdgcn_readfirstlane((int)s_surv);
         rp += plen;
         __syncthreads();
+        CH_MARK(5);
     }
     __syncthreads();
     if (tid0 == 0) {
@@ -275,6 +348,27 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
         if (s_split && __hip_atomic_load(&result[CHS_SPLIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
             __hip_atomic_store(&result[CHS_SPLIT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s_err) __hip_atomic_store(&result[CHS_ERR], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CH_PROFILE
+        for (int i = 0; i < 6; i++) atomicAdd(&result[64 + 8 * (c & 63) + i], (unsigned long long)pt[i]);      // spread: one address would serialise
+#endif
+    }
+#undef CH_MARK
+}
+
+// the longest Lyndon factor: (length modulo 2^32) << 32 | start
+__global__ __launch_bounds__(256) void factor_big_kernel(const u32 *__restrict__ fstart, u64 k, u64 n, u64 *__restrict__ fbig)
+{
+    __shared__ u64 bl[256], bs[256];
+    u64 bestL = 0, bestS = 0;
+    for (u64 f = threadIdx.x; f < k; f += 256) {
+        const u64 s0 = fstart[f], L = factor_end(fstart, k, n, f) - s0;
+        if (L > bestL) { bestL = L; bestS = s0; }
+    }
+    bl[threadIdx.x] = bestL; bs[threadIdx.x] = bestS;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 256; i++) if (bl[i] > bestL) { bestL = bl[i]; bestS = bs[i]; }
+        fbig[0] = ((u64)(u32)bestL << 32) | (u64)(u32)bestS;
     }
 }
 
@@ -477,6 +571,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u64 *mv = (u64 *)(base + 2 * e4);
     u32 *cstart = (u32 *)(base + 2 * e4 + e8), *ccount = (u32 *)(base + 2 * e4 + e8 + ct4), *mvcount = (u32 *)(base + 2 * e4 + e8 + 2 * ct4);
     u64 *slots = ctx->d_small + SM_CHSLOT;
+    u64 *fbig = ctx->d_small + SM_CHSLOT + CH_SLOTS * CH_SLOT_WORDS;      // one word behind the result slots
     const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
     PrevSym prev{sp.carry_src, d_T, n, d_fstart, k};
     u8 *out = CYCLIC ? sp.carry_out : nullptr;
@@ -534,6 +629,10 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         CH_HIP(hipMemcpyAsync(bl_idx[0], st_idx + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
         CH_HIP(hipMemcpyAsync(bl_head[0], st_head + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
     }
+    if (CYCLIC) {
+        factor_big_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(d_fstart, k, n, fbig);
+        CH_HIP(hipGetLastError());
+    }
     // ---- chunks over the smaller groups ----
     u32 nchunks = 0;
     u64 tail = a_small;                     // the store behind it is free: chunks leaving the big list are appended there
@@ -548,7 +647,11 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u64 a_chunks = a_small;                 // elements in chunks after the last evaluated round
     bool finished = false, stable = false;
     while (!finished) {
+#ifdef CH_PROFILE
+        const int B = 1;
+#else
         const int B = m_big ? 1 : 2;        // rounds per host round trip
+#endif
         CH_HIP(hipMemsetAsync(slots, 0, CH_SLOTS * CH_SLOT_WORDS * sizeof(u64), ctx->stream));
         u64 hs[CH_SLOTS];
         for (int b = 0; b < B; b++) {
@@ -558,10 +661,10 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 SpanGuard g(ctx, BWTS_K_ROUND, a_chunks, 32 * a_chunks);
                 if (nk == 3)
                     chunk_round_kernel<CYCLIC, 3><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, sp.rank, n, h,
-                                                                                                      d_fstart, k, prev, out, res);
+                                                                                                      d_fstart, k, fbig, prev, out, res);
                 else
                     chunk_round_kernel<CYCLIC, 1><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, sp.rank, n, h,
-                                                                                                      d_fstart, k, prev, out, res);
+                                                                                                      d_fstart, k, fbig, prev, out, res);
                 CH_HIP(hipGetLastError());
             }
             if (m_big) {
@@ -638,6 +741,17 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 if (m_exit + m_stay > m_big || tail + m_exit > a0) CH_FAIL("big list split counts");
             }
             if (in_chunks > a_chunks) CH_FAIL("chunks grew");
+#ifdef CH_PROFILE
+            if (round_trace && b == 0) {
+                (void)hipMemcpy(ctx->h_small + SM_CHSLOT + 64, ctx->d_small + SM_CHSLOT + 64, 64 * 8 * sizeof(u64), hipMemcpyDeviceToHost);
+                double ph[6] = {0, 0, 0, 0, 0, 0}, tot = 0;
+                for (int q = 0; q < 64; q++) for (int i = 0; i < 6; i++) ph[i] += (double)ctx->h_small[SM_CHSLOT + 64 + 8 * q + i];
+                for (int i = 0; i < 6; i++) tot += ph[i];
+                fprintf(stderr, "[chunks] phase shares: load %.1f%% detect %.1f%% gather %.1f%% count %.1f%% emit/moves %.1f%% write %.1f%%  (cycles per element %.2f)\n", 100 * ph[0] / tot, 100 * ph[1] / tot,
+                        100 * ph[2] / tot, 100 * ph[3] / tot, 100 * ph[4] / tot, 100 * ph[5] / tot, tot / (double)(a_chunks ? a_chunks : 1));
+                (void)hipMemset(ctx->d_small + SM_CHSLOT + 64, 0, 64 * 8 * sizeof(u64));
+            }
+#endif
             if (round_trace) fprintf(stderr, "[chunks] round %u h %llu: chunks %llu -> %llu, big list %llu -> stays %llu, leaves %llu\n", rounds,
                                      (unsigned long long)hs[b], (unsigned long long)a_chunks, (unsigned long long)in_chunks, (unsigned long long)m_big,
                                      (unsigned long long)m_stay, (unsigned long long)m_exit);
