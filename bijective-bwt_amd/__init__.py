@@ -19,7 +19,8 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libbwts_hip.so")
+# BWTS_LIB_OVERRIDE: another build of the same library (A/B timing sessions on one GPU box, tools/sessions/*.sh); never set in tests
+LIB_PATH = os.environ.get("BWTS_LIB_OVERRIDE") or os.path.join(PKG_DIR, "libbwts_hip.so")
 
 KINDS = {"uniform256": 0, "zipf": 1, "dna": 2, "text": 3}
 

@@ -18,7 +18,9 @@
 // the existing ones.  Groups only ever split, so an element is appended at most once and the chunk store never outgrows the list.
 #pragma once
 
+#ifndef CH_THREADS
 #define CH_THREADS 512
+#endif
 #define CH_ITEMS   4
 #define CH_TILE    (CH_THREADS * CH_ITEMS)
 #define CH_CAP     DG_CAP
@@ -27,27 +29,31 @@
 #ifndef CH_MIN_WAVES
 #define CH_MIN_WAVES 8
 #endif
-#define CH_FS      256                  // factors whose data a workgroup keeps in LDS (natural data has a dozen or two)
+#ifndef CH_FS
+#define CH_FS      256
+#endif
+// (factors whose data a workgroup keeps in LDS: natural data has a dozen or two)
 #define CH_MIN_LIST 65536ull            // shorter lists keep the tile form (dense_rounds)
 #define CH_SLOTS   4                    // result slots of rounds in flight
 #define CH_SLOT_WORDS 8
 #define SM_CHSLOT  (SM_DGCNT + 16)      // CH_SLOTS x CH_SLOT_WORDS words inside the dense rounds' counter block
 enum { CHS_SPLIT = 0, CHS_ERR = 1, CHS_TOTAL = 2, CHS_EXIT = 3, CHS_STAY = 4 };
 static_assert(CH_CAP * 4 <= CH_TILE, "a tile must hold several whole groups");
-static_assert(16 + CH_SLOTS * CH_SLOT_WORDS + 1 <= DG_CNT_BIG + DG_CNT_SPREAD, "result slots live in the dense rounds' counter block");
+static_assert(16 + CH_SLOTS * CH_SLOT_WORDS <= DG_CNT_BIG + DG_CNT_SPREAD, "result slots live in the dense rounds' counter block");
 
 // chunk c = list slots [cstart[c], cstart[c] + ccount[c]); the region up to cstart[c + 1] (or the store's tail) is its own.
-// The kernel is bound by its VALU instructions, not by memory (the first version needed ~750 per element: 1.9 TB/s of algorithmic
-// bytes), so everything per element is 32-bit arithmetic: positions are u32 (n <= 2^32; lengths are kept modulo 2^32, which the
-// wrap-around of the cyclic successor absorbs), the factor of a position is not searched for -- natural data has one factor that
-// holds most of the text: fbig = (its start, its length) and the step reduced modulo that length are wave-uniform, and only
-// positions outside it take the general 64-bit path -- and a slot's group extent comes from the wave's own __ballot word (which is
-// exactly the 64 slots of its lanes) plus two per-word neighbour values, not from a bit search over LDS per lane.
-template <bool CYCLIC, int NKEYS>
+// The kernel is bound by its VALU instructions as much as by memory (PMC on the first version: ~350 per element, VALU busy 51 %,
+// waves waiting 65 % of their cycles), so everything per element is 32-bit arithmetic: positions are u32 (n <= 2^32; lengths are
+// kept modulo 2^32, which the wrap-around of the cyclic successor absorbs); the factor of a position comes from a 256-entry
+// directory over the positions' top bits plus (nearly always) one comparison, and its start, length and the steps reduced
+// modulo the length from one 16-byte LDS read (FSL: at most CH_FS factors -- natural data has a dozen or two; inputs with more
+// take the instantiation with the general 64-bit arithmetic); and a slot's group extent comes from the wave's own __ballot word
+// (which is exactly the 64 slots of its lanes) plus two per-word neighbour values, not from a bit search over LDS per lane.
+template <bool CYCLIC, int NKEYS, bool FSL /* cyclic, at most CH_FS factors: their data sits in LDS */>
 __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u32 *idx, u32 *head, const u32 *__restrict__ cstart, u32 *__restrict__ ccount,
                                                                  u64 *__restrict__ mv, u32 *__restrict__ mvcount,
                                                                  const u32 *__restrict__ rank, u64 n, u64 h,
-                                                                 const u32 *__restrict__ fstart, u64 k, const u64 *__restrict__ fbig,
+                                                                 const u32 *__restrict__ fstart, u64 k,
                                                                  PrevSym prev, u8 *__restrict__ out, unsigned long long *__restrict__ result)
 {
     __shared__ u32 hd[CH_TILE];              // group heads of the tile
@@ -56,7 +62,9 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
     __shared__ u64 startm[CH_WORDS];         // bit = a group starts at this slot
     __shared__ u64 keepm[CH_WORDS];          // bit = the element sorted into this slot stays tied
     __shared__ u32 kpre[CH_WORDS];
-    __shared__ u32 ftab[CYCLIC ? 5 * CH_FS : 1];        // per factor: start, length (mod 2^32), the steps modulo the length
+    __shared__ uint4 ftab[FSL ? CH_FS + 1 : 1];         // per factor: start, length (mod 2^32), the steps h and 2h modulo the length
+    __shared__ u32 fhm3[FSL ? CH_FS : 1];               // ... and 3h
+    __shared__ u32 fdir[FSL ? 256 : 1];                 // factor that holds position b << dsh: a lookup starts there
     __shared__ u32 s_surv, s_nmv, s_split, s_err;
     const int tid0 = threadIdx.x;
     const u32 c = blockIdx.x;
@@ -64,32 +72,29 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
     const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)ccount[c]);
     if (cnt == 0) { if (tid0 == 0) mvcount[c] = 0; return; }
     if (tid0 == 0) { s_nmv = 0; s_split = 0; s_err = 0; }
-    // the step, wave-uniform.  CYCLIC: the longest factor [sB, sB + LB) (LB modulo 2^32: 0 = the whole 4 GiB) and the steps modulo
-    // its length; suffixes: p + j h < n  <=>  p < nhj
-    u32 sB = 0, LB = 0, hm1 = 0, hm2 = 0, hm3 = 0, nh1 = 0, nh2 = 0, nh3 = 0;
-    if (CYCLIC) {
-        const u64 fb = fbig[0];
-        sB = (u32)fb; LB = (u32)(fb >> 32);
-        const u64 L64 = LB ? (u64)LB : (1ull << 32);
-        hm1 = (u32)(h < L64 ? h : h % L64);
-        if (NKEYS == 3) { hm2 = (u32)(2 * h < L64 ? 2 * h : (2 * h) % L64); hm3 = (u32)(3 * h < L64 ? 3 * h : (3 * h) % L64); }
-    } else {
+    // the step, wave-uniform.  Cyclic with the factors in LDS: per factor the step(s) reduced modulo its length (a division only
+    // for factors shorter than the step: the short ones at the text's end), and a 256-entry directory over the positions' top bits
+    // so that finding a position's factor is one table read and (nearly always) one comparison.  Suffixes: p + j h < n <=> p < nhj.
+    u32 nh1 = 0, nh2 = 0, nh3 = 0;
+    const u32 h32 = (u32)h, k32 = (u32)k;
+    int dsh = 0;
+    if (FSL) {
+        for (u32 f = tid0; f < k32; f += CH_THREADS) {
+            const u64 s0 = fstart[f], L = (f + 1 < k32 ? (u64)fstart[f + 1] : n) - s0;
+            ftab[f] = make_uint4((u32)s0, (u32)L, (u32)(h < L ? h : h % L), NKEYS == 3 ? (u32)(2 * h < L ? 2 * h : (2 * h) % L) : 0u);
+            fhm3[f] = NKEYS == 3 ? (u32)(3 * h < L ? 3 * h : (3 * h) % L) : 0u;
+        }
+        { int bl = 0; for (u64 x = n - 1; x; x >>= 1) bl++; dsh = bl > 8 ? bl - 8 : 0; }
+        if (tid0 < 256) {
+            const u64 want = (u64)tid0 << dsh;
+            u32 lo = 0, hi = k32 - 1;
+            while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if ((u64)fstart[mid] <= want) lo = mid; else hi = mid - 1; }
+            fdir[tid0] = lo;
+        }
+    } else if (!CYCLIC) {
         nh1 = h < n ? (u32)(n - h) : 0u;            // (h >= 1, so n - h fits)
         if (NKEYS == 3) { nh2 = 2 * h < n ? (u32)(n - 2 * h) : 0u; nh3 = 3 * h < n ? (u32)(n - 3 * h) : 0u; }
     }
-    const u32 h32 = (u32)h;
-    const bool f_lds = CYCLIC && k <= CH_FS;
-    if (f_lds) {
-        // (a division only for factors shorter than the step: the short ones at the text's end)
-        for (u32 f = tid0; f < (u32)k; f += CH_THREADS) {
-            const u64 s0 = fstart[f], L = (f + 1 < (u32)k ? (u64)fstart[f + 1] : n) - s0;
-            ftab[f] = (u32)s0; ftab[CH_FS + f] = (u32)L;
-            ftab[2 * CH_FS + f] = (u32)(h < L ? h : h % L);
-            ftab[3 * CH_FS + f] = NKEYS == 3 ? (u32)(2 * h < L ? 2 * h : (2 * h) % L) : 0u;
-            ftab[4 * CH_FS + f] = NKEYS == 3 ? (u32)(3 * h < L ? 3 * h : (3 * h) % L) : 0u;
-        }
-    }
-    const u32 k32 = (u32)k;
     u32 rp = 0, wp = 0;                      // read / write cursors inside the chunk (uniform)
 #ifdef CH_PROFILE
     long long pt[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
@@ -130,32 +135,20 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
             if ((u32)j * CH_THREADS + tid >= len) continue;
             const u32 p = myp[j];
             if (CYCLIC) {
-                const u32 d = p - sB;                  // (p < sB wraps to a value >= LB)
                 u32 q1, q2 = 0, q3 = 0;
-                if (LB == 0 || d < LB) {
-                    // inside the longest factor: offset + step, minus the length when the sum passes it (a carry out of 32 bits
-                    // passes it too; with LB = 0 the subtraction does nothing and the wrapped sum is already right)
-                    ppos[j] = d ? p - 1u : sB + LB - 1u;
-                    u32 o = d + hm1;
-                    o = (o < d || o >= LB) ? o - LB : o;
-                    q1 = sB + o;
-                    if (NKEYS == 3) {
-                        u32 o2 = d + hm2, o3 = d + hm3;
-                        o2 = (o2 < d || o2 >= LB) ? o2 - LB : o2;
-                        o3 = (o3 < d || o3 >= LB) ? o3 - LB : o3;
-                        q2 = sB + o2; q3 = sB + o3;
-                    }
-                } else if (f_lds) {
-                    // another factor: binary search over the starts in LDS, then the same 32-bit arithmetic with its own length and steps
-                    u32 lo = 0, hi = k32 - 1;
-                    while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (ftab[mid] <= p) lo = mid; else hi = mid - 1; }
-                    const u32 s0 = ftab[lo], L = ftab[CH_FS + lo], dd = p - s0;
+                if (FSL) {
+                    // offset in the factor + step, minus the factor's length when the sum passes it (a carry out of 32 bits passes
+                    // it too; a length of 2^32 is kept as 0: the subtraction then does nothing and the wrapped sum is already right)
+                    u32 f = fdir[p >> dsh];
+                    while (f + 1 < k32 && ftab[f + 1].x <= p) f++;
+                    const uint4 ft = ftab[f];
+                    const u32 s0 = ft.x, L = ft.y, dd = p - s0;
                     ppos[j] = dd ? p - 1u : s0 + L - 1u;
-                    u32 o = dd + ftab[2 * CH_FS + lo];
+                    u32 o = dd + ft.z;
                     o = (o < dd || o >= L) ? o - L : o;
                     q1 = s0 + o;
                     if (NKEYS == 3) {
-                        u32 o2 = dd + ftab[3 * CH_FS + lo], o3 = dd + ftab[4 * CH_FS + lo];
+                        u32 o2 = dd + ft.w, o3 = dd + fhm3[f];
                         o2 = (o2 < dd || o2 >= L) ? o2 - L : o2;
                         o3 = (o3 < dd || o3 >= L) ? o3 - L : o3;
                         q2 = s0 + o2; q3 = s0 + o3;
@@ -353,23 +346,6 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
 #endif
     }
 #undef CH_MARK
-}
-
-// the longest Lyndon factor: (length modulo 2^32) << 32 | start
-__global__ __launch_bounds__(256) void factor_big_kernel(const u32 *__restrict__ fstart, u64 k, u64 n, u64 *__restrict__ fbig)
-{
-    __shared__ u64 bl[256], bs[256];
-    u64 bestL = 0, bestS = 0;
-    for (u64 f = threadIdx.x; f < k; f += 256) {
-        const u64 s0 = fstart[f], L = factor_end(fstart, k, n, f) - s0;
-        if (L > bestL) { bestL = L; bestS = s0; }
-    }
-    bl[threadIdx.x] = bestL; bs[threadIdx.x] = bestS;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 256; i++) if (bl[i] > bestL) { bestL = bl[i]; bestS = bs[i]; }
-        fbig[0] = ((u64)(u32)bestL << 32) | (u64)(u32)bestS;
-    }
 }
 
 // rank[position] = new rank for everything a round moved; runs when every gather of the round is done
@@ -571,7 +547,6 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u64 *mv = (u64 *)(base + 2 * e4);
     u32 *cstart = (u32 *)(base + 2 * e4 + e8), *ccount = (u32 *)(base + 2 * e4 + e8 + ct4), *mvcount = (u32 *)(base + 2 * e4 + e8 + 2 * ct4);
     u64 *slots = ctx->d_small + SM_CHSLOT;
-    u64 *fbig = ctx->d_small + SM_CHSLOT + CH_SLOTS * CH_SLOT_WORDS;      // one word behind the result slots
     const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
     PrevSym prev{sp.carry_src, d_T, n, d_fstart, k};
     u8 *out = CYCLIC ? sp.carry_out : nullptr;
@@ -629,10 +604,6 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         CH_HIP(hipMemcpyAsync(bl_idx[0], st_idx + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
         CH_HIP(hipMemcpyAsync(bl_head[0], st_head + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (CYCLIC) {
-        factor_big_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(d_fstart, k, n, fbig);
-        CH_HIP(hipGetLastError());
-    }
     // ---- chunks over the smaller groups ----
     u32 nchunks = 0;
     u64 tail = a_small;                     // the store behind it is free: chunks leaving the big list are appended there
@@ -659,12 +630,12 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             hs[b] = h;
             if (nchunks) {
                 SpanGuard g(ctx, BWTS_K_ROUND, a_chunks, 32 * a_chunks);
-                if (nk == 3)
-                    chunk_round_kernel<CYCLIC, 3><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, sp.rank, n, h,
-                                                                                                      d_fstart, k, fbig, prev, out, res);
-                else
-                    chunk_round_kernel<CYCLIC, 1><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, sp.rank, n, h,
-                                                                                                      d_fstart, k, fbig, prev, out, res);
+#define CH_LAUNCH(NK, FS) chunk_round_kernel<CYCLIC, NK, FS><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, sp.rank, n, h, \
+                                                                                                        d_fstart, k, prev, out, res)
+                const bool fsl = CYCLIC && k <= CH_FS;
+                if (nk == 3) { if (fsl) CH_LAUNCH(3, CYCLIC); else CH_LAUNCH(3, false); }
+                else { if (fsl) CH_LAUNCH(1, CYCLIC); else CH_LAUNCH(1, false); }
+#undef CH_LAUNCH
                 CH_HIP(hipGetLastError());
             }
             if (m_big) {

@@ -292,12 +292,22 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
                         if (1.0 - exp(-partners) <= 1.0 / 64.0) { kb_emp = b; break; }
                     }
                     if (kb_emp > kb) {
-                        kb = kb_emp;
-                        // the fixed-width alternative was sized by the same model: let it use every symbol that fits
-                        al->msym = 64 / bits;
-                        al->key_bits = al->bits * al->msym;
-                        al->hstep = al->msym;
-                        al->patch_span = al->msym - 1;
+                        // Repeats, not entropy, tie these positions, and no key width separates the copies of a long repeat: the
+                        // rounds on the tied list will.  Wider keys then only pay where they lengthen the first step (key bits /
+                        // longest code word) -- with short code words the model's width, at least five digits, already gives a step
+                        // of four symbols, and three fewer n-sized passes beat the few per cent of extra list elements (text 2^30,
+                        // longest code 9 bits: 64 / 48 / 40 / 32 key bits = 169 / 160 / 143 / 159 ms); with long code words (real
+                        // text: 205 symbols, 16 bits) every key bit counts (53.6 MiB: 16.1 / 18.5 / 20.6 / 23.3 ms).
+                        const int keep = kb < 40 ? 40 : kb;
+                        if (keep / lmax >= 4) kb = keep;
+                        else {
+                            kb = kb_emp;
+                            // the fixed-width alternative was sized by the same model: let it use every symbol that fits
+                            al->msym = 64 / bits;
+                            al->key_bits = al->bits * al->msym;
+                            al->hstep = al->msym;
+                            al->patch_span = al->msym - 1;
+                        }
                     }
                 }
             }

@@ -324,7 +324,7 @@ def test_errors(ctx, pkg):
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json sizes: size-independent properties
 # ---------------------------------------------------------------------------------------------
-def _properties_at_scale(ctx, kind, n, seed):
+def _properties_at_scale(ctx, kind, n, seed, golden=False):
     d_in, d_out, d_back = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
     try:
         ctx.generate(kind, seed, n, d_in)
@@ -337,6 +337,13 @@ def _properties_at_scale(ctx, kind, n, seed):
         x, y = d_in.download(), d_out.download()
         assert np.array_equal(np.bincount(x, minlength=256), np.bincount(y, minlength=256))
         assert y[0] == x[-1]
+        # (2b) byte-exact against the oracle where its output at this size is on file (tests/golden/big_forward.json: the pinned
+        # CPU restatement of mk_bwts_sa.c:114-195 run in the build container by make_golden_big.py)
+        gold = [r for r in BIG["cases"] if r["kind"] == kind and r["n"] == n and r["seed"] == seed]
+        if golden:
+            assert gold, "no golden for %s(%d, %d)" % (kind, n, seed)
+            assert hashlib.sha256(x.tobytes()).hexdigest() == gold[0]["sha256_in"]
+            assert hashlib.sha256(y.tobytes()).hexdigest() == gold[0]["sha256_bwts"]
         # (4) the generator stream is what the oracle generates (spot check both ends)
         assert np.array_equal(x[:4096], O.generate(kind, 4096, seed))
         assert np.array_equal(x[-4096:], O.generate(kind, 4096, seed, off=n - 4096))
@@ -350,13 +357,15 @@ def _properties_at_scale(ctx, kind, n, seed):
             b.free()
 
 
-def test_config2_uniform_256MiB_properties(ctx):
-    tf = _properties_at_scale(ctx, "uniform256", 1 << 28, 1)
+def test_config2_uniform_256MiB_golden_and_properties(ctx):
+    """BASELINE config 2, byte-exact: sha-256 of the device's output == the oracle's (golden), then the properties."""
+    tf = _properties_at_scale(ctx, "uniform256", 1 << 28, 1, golden=True)
     assert tf.factors >= 1
 
 
-def test_config3_zipf_1GiB_properties(ctx):
-    _properties_at_scale(ctx, "zipf", 1 << 30, 1)
+def test_config3_zipf_1GiB_golden_and_properties(ctx):
+    """BASELINE config 3 (the headline workload), byte-exact against the oracle's golden, then the properties."""
+    _properties_at_scale(ctx, "zipf", 1 << 30, 1, golden=True)
 
 
 def test_index_boundary_2p31(ctx):
@@ -740,8 +749,9 @@ def test_text_16MiB_vs_oracle(ctx):
     assert np.array_equal(ctx.inverse(y), x)
 
 
-def test_text_1GiB_properties(ctx):
-    _properties_at_scale(ctx, "text", 1 << 30, 1)
+def test_text_1GiB_golden_and_properties(ctx):
+    """The bench's text workload at full size, byte-exact against the oracle's golden, then the properties."""
+    _properties_at_scale(ctx, "text", 1 << 30, 1, golden=True)
 
 
 # ---------------------------------------------------------------------------------------------
