@@ -226,7 +226,7 @@ def _e2e(ctx, helper, d_in, d_out, n, workload):
             res["cli_wall_MBps"] = round(n / 1e6 / a["wall_s"], 1) if a["rc"] == 0 else None
             res["cli_inverse_wall_MBps"] = round(n / 1e6 / b["wall_s"], 1) if b["rc"] == 0 else None
             res["cli_wall_s"] = {"mk_bwts": round(a["wall_s"], 3), "unbwts": round(b["wall_s"], 3)}
-            res["cli_phases"] = [l for l in a["stderr"].splitlines() if " time " in l][-6:]
+            res["cli_phases"] = [l for l in a["stderr"].splitlines() if " time " in l][-7:]
             if ok:
                 res["cli_output_equals_device_path"] = bool(np.array_equal(np.fromfile(out, dtype=np.uint8), ymem))
                 res["cli_roundtrip_exact"] = bool(np.array_equal(np.fromfile(rt, dtype=np.uint8), x))

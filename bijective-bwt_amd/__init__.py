@@ -28,12 +28,14 @@ K_NAMES = ["histogram", "keybuild", "radix_hist", "radix_scan", "radix_scatter",
            "lf_build", "walk", "listrank", "walk_emit", "other", "radix_scatter_main", "round"]
 K_COUNT = len(K_NAMES)
 MAX_ROUND_STATS = 40
+H_NAMES = ["init", "module_load", "io_alloc", "staging_alloc", "arena_alloc"]
+H_COUNT = len(H_NAMES)
 
 # every symbol include/bwts.h declares (the drop-in surface) ...
 EXPORTS = [
     "bwts_ctx_create", "bwts_ctx_destroy", "bwts_forward", "bwts_inverse", "bwts_forward_sink", "bwts_inverse_sink",
     "bwts_forward_device", "bwts_inverse_device", "bwts_last_timings", "bwts_kernel_class_name", "bwts_strerror",
-    "bwts_last_hip_error", "bwts_set_timing", "bwts_host_alloc", "bwts_host_free",
+    "bwts_last_hip_error", "bwts_set_timing", "bwts_host_alloc", "bwts_host_free", "bwts_host_cost_name",
 ]
 # ... and include/bwts_test.h (harness and unit-test hooks)
 TEST_EXPORTS = [
@@ -58,10 +60,12 @@ class Timings(ctypes.Structure):
                 ("n", ctypes.c_uint64), ("factors", ctypes.c_uint64), ("rounds", ctypes.c_uint32),
                 ("lyndon_rounds", ctypes.c_uint32), ("key_symbols", ctypes.c_uint32), ("key_bits", ctypes.c_uint32),
                 ("active_after_round0", ctypes.c_uint64), ("unvisited", ctypes.c_uint64), ("device_bytes", ctypes.c_uint64),
-                ("round_active", ctypes.c_uint64 * MAX_ROUND_STATS), ("k", KernelStat * K_COUNT)]
+                ("round_active", ctypes.c_uint64 * MAX_ROUND_STATS), ("k", KernelStat * K_COUNT),
+                ("host_ms", ctypes.c_double * H_COUNT)]
 
     def as_dict(self):
-        d = {f: getattr(self, f) for f, _ in self._fields_ if f not in ("k", "round_active")}
+        d = {f: getattr(self, f) for f, _ in self._fields_ if f not in ("k", "round_active", "host_ms")}
+        d["host_ms"] = {H_NAMES[i]: float(self.host_ms[i]) for i in range(H_COUNT)}
         d["round_active"] = [int(v) for v in self.round_active[: max(int(self.rounds), 1)]]
         d["kernels"] = {K_NAMES[i]: {"ms": self.k[i].ms, "launches": self.k[i].launches, "elems": self.k[i].elems,
                                      "alg_bytes": self.k[i].alg_bytes} for i in range(K_COUNT) if self.k[i].launches}

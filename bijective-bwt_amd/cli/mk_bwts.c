@@ -41,56 +41,74 @@ static double now_s(void)
 
 static double write_s;
 
-static int write_piece(void *user, const uint8_t *data, uint64_t len)
-{
-	const double t0 = now_s();
-	const size_t done = fwrite(data, 1, (size_t)len, (FILE *)user);
-	write_s += now_s() - t0;
-	return done == (size_t)len ? 0 : 1;
-}
-
-static FILE *open_output(const char *explicit_name, const char *in_name)
-{
+/* The output is opened by the first piece that arrives (the reference computes first and opens afterwards, mk_bwts_sa.c:47-60):
+ * by then the whole input has been read, so `mk_bwts f f` works, and a transform that fails leaves no truncated destination. */
+struct out_file {
+	const char *explicit_name, *in_name;
 	FILE *fp;
+	char *auto_name;        /* name made by mkstemps (removed again if the transform fails) */
+	int failed;
+};
 
-	if (explicit_name) {
+static void open_output(struct out_file *o)
+{
+	if (o->explicit_name) {
 #ifdef BWTS_AUTONAME
-		fp = fopen(explicit_name, "wb");
+		o->fp = fopen(o->explicit_name, "wb");
 #else
-		fp = fopen(explicit_name, "w");
+		o->fp = fopen(o->explicit_name, "w");
 #endif
-		if (!fp) {
+		if (!o->fp) {
 			fprintf(stderr, "Couldn't open BWTS file for writing\n");
-			perror(explicit_name);
-			exit(1);
+			perror(o->explicit_name);
+			o->failed = 1;
 		}
-		return fp;
+		return;
 	}
 #ifdef BWTS_AUTONAME
 	{
-		char *name = NULL;
 		int fd;
 
-		if (asprintf(&name, "%s_XXXXXX.bwts", in_name) <= 0) {
+		if (asprintf(&o->auto_name, "%s_XXXXXX.bwts", o->in_name) <= 0) {
 			fprintf(stderr, "Allocating outfile name failed. Abort\n");
-			exit(1);
+			o->auto_name = NULL;
+			o->failed = 1;
+			return;
 		}
-		fd = mkstemps(name, 5);
-		printf("Writing to %s\n", name);
+		fd = mkstemps(o->auto_name, 5);
+		printf("Writing to %s\n", o->auto_name);
 		fflush(stdout);
-		fp = fd >= 0 ? fdopen(fd, "w") : NULL;
-		if (!fp) {
+		o->fp = fd >= 0 ? fdopen(fd, "w") : NULL;
+		if (!o->fp) {
 			fprintf(stderr, "Couldn't open BWTS file for writing\n");
-			perror(name);
-			exit(1);
+			perror(o->auto_name);
+			o->failed = 1;
 		}
-		free(name);
-		return fp;
 	}
 #else
-	(void)in_name;
-	return stdout;
+	o->fp = stdout;
 #endif
+}
+
+static int write_piece(void *user, const uint8_t *data, uint64_t len)
+{
+	struct out_file *o = (struct out_file *)user;
+	double t0;
+	size_t done;
+
+	if (!o->fp && !o->failed)
+		open_output(o);
+	if (o->failed)
+		return 1;
+	t0 = now_s();
+	done = fwrite(data, 1, (size_t)len, o->fp);
+	write_s += now_s() - t0;
+	if (done != (size_t)len) {
+		perror("write");
+		o->failed = 1;
+		return 1;
+	}
+	return 0;
 }
 
 int main(int argc, char **argv)
@@ -98,7 +116,7 @@ int main(int argc, char **argv)
 	unsigned char *text;
 	long len;
 	bwts_ctx *ctx;
-	FILE *fp;
+	struct out_file o;
 	int rc;
 	const char *dev = getenv("BWTS_DEVICE");
 	const char *show_env = getenv("BWTS_TIMINGS");
@@ -124,15 +142,24 @@ int main(int argc, char **argv)
 		fail("cannot open GPU context", rc);
 	if (show)
 		bwts_set_timing(ctx, 2);
-	fp = open_output(argc < 3 ? NULL : argv[2], argv[1]);
+	memset(&o, 0, sizeof o);
+	o.explicit_name = argc < 3 ? NULL : argv[2];
+	o.in_name = argv[1];
 
 	t_start = now_s();
-	if ((rc = bwts_forward_sink(ctx, text, (uint64_t)len, write_piece, fp)) != BWTS_OK)
-		fail("transform failed", rc);
-	if (fp != stdout)
-		fclose(fp);
-	else
-		fflush(fp);
+	rc = bwts_forward_sink(ctx, text, (uint64_t)len, write_piece, &o);
+	if (rc == BWTS_OK && o.fp && (o.fp != stdout ? fclose(o.fp) : fflush(o.fp)) != 0) {
+		perror("write");
+		o.failed = 1;
+	}
+	if (rc != BWTS_OK || o.failed) {
+		/* nothing half-written stays behind under a name this run made up */
+		if (o.auto_name)
+			unlink(o.auto_name);
+		if (rc != BWTS_OK && !o.failed)
+			fail("transform failed", rc);
+		exit(1);
+	}
 	t_wall = now_s() - t_start;
 
 	if (show) {
@@ -150,6 +177,13 @@ int main(int argc, char **argv)
 		fprintf(stderr, "Write BWTS time %0.3f\n", 1e-3 * t.d2h_ms);
 		fprintf(stderr, "Transform (device) time %0.3f  H2D %0.3f  D2H+write %0.3f (fwrite %0.3f)  wall %0.3f\n", 1e-3 * t.total_ms,
 			1e-3 * t.h2d_ms, 1e-3 * t.d2h_ms, write_s, t_wall);
+		/* what a one-shot run pays outside kernels and copies */
+		fprintf(stderr, "Start-up time %0.3f  (HIP runtime + context %0.3f, code object load %0.3f)  allocation time %0.3f  (device in/out %0.3f, "
+			"pinned staging %0.3f, arenas %0.3f; %0.1f GiB on the device)\n",
+			1e-3 * (t.host_ms[BWTS_H_INIT] + t.host_ms[BWTS_H_MODULE]), 1e-3 * t.host_ms[BWTS_H_INIT], 1e-3 * t.host_ms[BWTS_H_MODULE],
+			1e-3 * (t.host_ms[BWTS_H_IO_ALLOC] + t.host_ms[BWTS_H_STAGING_ALLOC] + t.host_ms[BWTS_H_ARENA_ALLOC]),
+			1e-3 * t.host_ms[BWTS_H_IO_ALLOC], 1e-3 * t.host_ms[BWTS_H_STAGING_ALLOC], 1e-3 * t.host_ms[BWTS_H_ARENA_ALLOC],
+			(double)t.device_bytes / (double)(1ull << 30));
 	}
 	bwts_ctx_destroy(ctx);
 	return 0;

@@ -19,44 +19,59 @@
 #include "bwts.h"
 #include "map_file.h"
 
-static FILE *open_output(const char *explicit_name, const char *in_name)
-{
+/* The output is opened by the first piece that arrives (the reference computes first and calls write_out() afterwards,
+ * unbwts.c:62-89): by then the whole input has been read, so `unbwts f f` works, and a failing transform leaves nothing behind. */
+struct out_file {
+	const char *explicit_name, *in_name;
 	FILE *fp;
+	char *auto_name;
+	int failed;
+};
 
-	if (explicit_name) {
-		fp = fopen(explicit_name, "wb");
-		if (!fp) {
+static void open_output(struct out_file *o)
+{
+	int fd;
+
+	if (o->explicit_name) {
+		o->fp = fopen(o->explicit_name, "wb");
+		if (!o->fp) {
 			fprintf(stderr, "Couldn't open output file for writing\n");
-			perror(explicit_name);
-			exit(1);
+			perror(o->explicit_name);
+			o->failed = 1;
 		}
-		return fp;
+		return;
 	}
-	{
-		char *name = NULL;
-		int fd;
-
-		if (asprintf(&name, "%s_XXXXXX", in_name) <= 0) {
-			fprintf(stderr, "Allocating outfile name failed. Abort\n");
-			exit(1);
-		}
-		fd = mkstemps(name, 0);
-		printf("Writing to %s\n", name);
-		fflush(stdout);
-		fp = fd >= 0 ? fdopen(fd, "w") : NULL;
-		if (!fp) {
-			fprintf(stderr, "Couldn't open output file for writing\n");
-			perror(name);
-			exit(1);
-		}
-		free(name);
-		return fp;
+	if (asprintf(&o->auto_name, "%s_XXXXXX", o->in_name) <= 0) {
+		fprintf(stderr, "Allocating outfile name failed. Abort\n");
+		o->auto_name = NULL;
+		o->failed = 1;
+		return;
+	}
+	fd = mkstemps(o->auto_name, 0);
+	printf("Writing to %s\n", o->auto_name);
+	fflush(stdout);
+	o->fp = fd >= 0 ? fdopen(fd, "w") : NULL;
+	if (!o->fp) {
+		fprintf(stderr, "Couldn't open output file for writing\n");
+		perror(o->auto_name);
+		o->failed = 1;
 	}
 }
 
 static int write_piece(void *user, const uint8_t *data, uint64_t len)
 {
-	return fwrite(data, 1, (size_t)len, (FILE *)user) == (size_t)len ? 0 : 1;
+	struct out_file *o = (struct out_file *)user;
+
+	if (!o->fp && !o->failed)
+		open_output(o);
+	if (o->failed)
+		return 1;
+	if (fwrite(data, 1, (size_t)len, o->fp) != (size_t)len) {
+		perror("write");
+		o->failed = 1;
+		return 1;
+	}
+	return 0;
 }
 
 int main(int argc, char **argv)
@@ -64,7 +79,7 @@ int main(int argc, char **argv)
 	unsigned char *bwts;
 	long len;
 	bwts_ctx *ctx;
-	FILE *fp;
+	struct out_file o;
 	int rc;
 	const char *dev = getenv("BWTS_DEVICE");
 	const char *show = getenv("BWTS_TIMINGS");
@@ -80,12 +95,21 @@ int main(int argc, char **argv)
 		fprintf(stderr, "unbwts: %s\n", bwts_strerror(rc));
 		exit(1);
 	}
-	fp = open_output(argc < 3 ? NULL : argv[2], argv[1]);
-	if ((rc = bwts_inverse_sink(ctx, bwts, (uint64_t)len, write_piece, fp)) != BWTS_OK) {
-		fprintf(stderr, "unbwts: %s\n", bwts_strerror(rc));
+	memset(&o, 0, sizeof o);
+	o.explicit_name = argc < 3 ? NULL : argv[2];
+	o.in_name = argv[1];
+	rc = bwts_inverse_sink(ctx, bwts, (uint64_t)len, write_piece, &o);
+	if (rc == BWTS_OK && o.fp && fclose(o.fp) != 0) {
+		perror("write");
+		o.failed = 1;
+	}
+	if (rc != BWTS_OK || o.failed) {
+		if (o.auto_name)
+			unlink(o.auto_name);        /* nothing half-written stays behind under a name this run made up */
+		if (rc != BWTS_OK && !o.failed)
+			fprintf(stderr, "unbwts: %s\n", bwts_strerror(rc));
 		exit(1);
 	}
-	fclose(fp);
 	if (show && show[0] == '1') {
 		bwts_timings t;
 		bwts_last_timings(ctx, &t);

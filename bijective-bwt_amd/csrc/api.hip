@@ -8,6 +8,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+double wall_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+
 void bwts_trace_error(const char *file, int line, int rc)
 {
     static const bool on = [] { const char *e = getenv("BWTS_TRACE_ERRORS"); return e && e[0] == '1'; }();
@@ -21,11 +28,13 @@ int arena_reserve(bwts_ctx *ctx, size_t bytes)
 {
     bytes = align_up(bytes, 1 << 20);
     if (bytes > ctx->arena_cap) {
+        const double t0 = wall_ms();
         if (ctx->arena) { HIPC(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
         ctx->arena = (char *)p;
         ctx->arena_cap = bytes;
+        ctx->host_ms[BWTS_H_ARENA_ALLOC] += wall_ms() - t0;
     }
     ctx->arena_off = 0;
     return BWTS_OK;
@@ -46,12 +55,14 @@ int aux_reserve_slot(bwts_ctx *ctx, int slot, size_t bytes, char **base)
 {
     bytes = align_up(bytes, 1 << 20);
     if (bytes > ctx->aux_cap[slot]) {
+        const double t0 = wall_ms();
         // contents of a previous, smaller block are never live across this call
         if (ctx->aux[slot]) { HIPC(hipStreamSynchronize(ctx->stream)); HIPC(hipFree(ctx->aux[slot])); ctx->aux[slot] = nullptr; ctx->aux_cap[slot] = 0; }
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
         ctx->aux[slot] = (char *)p;
         ctx->aux_cap[slot] = bytes;
+        ctx->host_ms[BWTS_H_ARENA_ALLOC] += wall_ms() - t0;
     }
     *base = ctx->aux[slot];
     return BWTS_OK;
@@ -131,6 +142,7 @@ extern "C" int bwts_ctx_create(bwts_ctx **out, int device_id)
 {
     if (!out) return BWTS_E_ARG;
     *out = nullptr;
+    const double t_create = wall_ms();
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return BWTS_E_NODEVICE; }
     if (device_id < 0 || device_id >= count) return BWTS_E_NODEVICE;
@@ -147,6 +159,7 @@ extern "C" int bwts_ctx_create(bwts_ctx **out, int device_id)
     if (hipHostMalloc(&p, 4096 * sizeof(u64), hipHostMallocDefault) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_NOMEM; }
     ctx->h_small = (u64 *)p;
     if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_HIP; }
+    ctx->host_ms[BWTS_H_INIT] = wall_ms() - t_create;
     *out = ctx;
     return BWTS_OK;
 }
@@ -160,7 +173,7 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->arena) (void)hipFree(ctx->arena);
-    for (int i = 0; i < 2; i++) if (ctx->aux[i]) (void)hipFree(ctx->aux[i]);
+    for (int i = 0; i < BWTS_AUX_SLOTS; i++) if (ctx->aux[i]) (void)hipFree(ctx->aux[i]);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
@@ -180,6 +193,7 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
 // transforms
 // ------------------------------------------------------------------------------------
 typedef int (*device_impl_fn)(bwts_ctx *, const u8 *, u64, u8 *);
+__global__ void pcie_copy_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, u64 vecs, u8 *__restrict__ dst_tail, const u8 *__restrict__ src_tail, u32 tail);
 
 static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n, void *d_out)
 {
@@ -188,6 +202,14 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
     spans_reset(ctx);
     ctx->tm.n = n;
     ctx->call_block_bytes = 0;
+    if (!ctx->launched) {
+        // the library's code object is loaded at the first launch: pay (and account for) that outside the timed transform
+        const double t0 = wall_ms();
+        pcie_copy_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(nullptr, nullptr, 0, nullptr, nullptr, 0);
+        HIPC(hipStreamSynchronize(ctx->stream));
+        ctx->host_ms[BWTS_H_MODULE] += wall_ms() - t0;
+        ctx->launched = true;
+    }
     HIPC(hipEventRecord(ctx->ev_begin, ctx->stream));
     int rc = fn(ctx, (const u8 *)d_in, n, (u8 *)d_out);
     if (rc != BWTS_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
@@ -196,7 +218,8 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
     float ms = 0.f;
     HIPC(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     ctx->tm.total_ms = ms;
-    ctx->tm.device_bytes = ctx->arena_cap + ctx->aux_cap[0] + ctx->aux_cap[1] + ctx->d_io_cap[0] + ctx->d_io_cap[1] + ctx->call_block_bytes;
+    ctx->tm.device_bytes = ctx->arena_cap + ctx->d_io_cap[0] + ctx->d_io_cap[1] + ctx->call_block_bytes;
+    for (int i = 0; i < BWTS_AUX_SLOTS; i++) ctx->tm.device_bytes += ctx->aux_cap[i];
     return BWTS_OK;
 }
 
@@ -341,6 +364,8 @@ static int pcie_copy(bwts_ctx *ctx, void *dst, const void *src, size_t len, bool
 
 static int ensure_staging(bwts_ctx *ctx)
 {
+    const double t0 = wall_ms();
+    const bool first = !ctx->pool;
     for (int i = 0; i < STAGE_SLOTS; i++) {
         if (!ctx->pinned[i]) {
             void *p = nullptr;
@@ -361,6 +386,7 @@ static int ensure_staging(bwts_ctx *ctx)
         if (!ctx->pool) return BWTS_E_NOMEM;
         ctx->pool->start(threads);
     }
+    if (first) ctx->host_ms[BWTS_H_STAGING_ALLOC] += wall_ms() - t0;
     return BWTS_OK;
 }
 
@@ -438,16 +464,11 @@ static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n, bwts_sin
     return rc;
 }
 
-static double wall_ms(void)
-{
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
-}
 
 // device-side copies of the caller's input and output stay with the context (grown, never shrunk)
 static int ensure_io(bwts_ctx *ctx, u64 n)
 {
+    const double t0 = wall_ms();
     for (int i = 0; i < 2; i++) {
         if (ctx->d_io_cap[i] >= n) continue;
         if (ctx->d_io[i]) { HIPC(hipFree(ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
@@ -457,6 +478,7 @@ static int ensure_io(bwts_ctx *ctx, u64 n)
         ctx->d_io[i] = (u8 *)p;
         ctx->d_io_cap[i] = cap;
     }
+    ctx->host_ms[BWTS_H_IO_ALLOC] += wall_ms() - t0;
     return BWTS_OK;
 }
 
@@ -465,8 +487,18 @@ static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_
     if (!ctx || !in || (!out && !sink) || n == 0) return BWTS_E_ARG;
     HIPC(hipSetDevice(ctx->device));
     BWTS_TRY(ensure_io(ctx, n));
+    // a context's first call allocates its arena, which costs as long as the whole input copy (the driver clears what it hands
+    // out): a helper thread does it while this one stages the input
+    const size_t want = n <= 0x100000000ull ? (fn == forward_device_impl ? forward_arena_bytes(n) : inverse_arena_bytes(n)) : 0;
+    std::thread reserve;
+    int reserve_rc = BWTS_OK;
+    if (want > ctx->arena_cap)
+        reserve = std::thread([ctx, want, &reserve_rc] { if (hipSetDevice(ctx->device) == hipSuccess) reserve_rc = arena_reserve(ctx, want); });
     double t0 = wall_ms();
-    BWTS_TRY(staged_h2d(ctx, ctx->d_io[0], in, n));
+    const int h2d_rc = staged_h2d(ctx, ctx->d_io[0], in, n);
+    if (reserve.joinable()) reserve.join();
+    BWTS_TRY(h2d_rc);
+    if (reserve_rc != BWTS_OK && reserve_rc != BWTS_E_NOMEM) return reserve_rc;       // (out of memory: the transform's own reservation reports it)
     const double h2d = wall_ms() - t0;
     // the caller's output buffer is usually fresh: its page faults are taken by the copy workers during the transform
     const bool touch = !sink && !is_pinned_block(ctx, out, n) && ensure_staging(ctx) == BWTS_OK;
@@ -543,6 +575,7 @@ extern "C" int bwts_last_timings(bwts_ctx *ctx, bwts_timings *t)
 {
     if (!ctx || !t) return BWTS_E_ARG;
     *t = ctx->tm;
+    for (int i = 0; i < BWTS_H_COUNT; i++) t->host_ms[i] = ctx->host_ms[i];
     return BWTS_OK;
 }
 
@@ -551,6 +584,12 @@ extern "C" const char *bwts_kernel_class_name(int k)
     static const char *names[BWTS_K_COUNT] = {"histogram", "keybuild", "radix_hist", "radix_scan", "radix_scatter", "rerank",
                                               "lyndon", "emit", "lf_build", "walk", "listrank", "walk_emit", "other", "radix_scatter_main", "round"};
     return (k >= 0 && k < BWTS_K_COUNT) ? names[k] : "?";
+}
+
+extern "C" const char *bwts_host_cost_name(int h)
+{
+    static const char *names[BWTS_H_COUNT] = {"init", "module_load", "io_alloc", "staging_alloc", "arena_alloc"};
+    return (h >= 0 && h < BWTS_H_COUNT) ? names[h] : "?";
 }
 
 extern "C" const char *bwts_strerror(int code)

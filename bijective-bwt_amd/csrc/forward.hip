@@ -1102,7 +1102,18 @@ struct SortSpace {
 
 static size_t sort_space_bytes(u64 n)
 {
-    return 2 * align_up(n * 8, 256) + 3 * align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 4096;
+    return 2 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + 4096;
+}
+
+// the dense rank array (4 n bytes) exists only for inputs that need it: many ties after round 0, a suffix array with ranks, or a
+// sort without the carried-byte buffers (whose space the round-0 flag words otherwise use)
+static int ensure_rank(bwts_ctx *ctx, SortSpace &sp, u64 n)
+{
+    if (sp.rank) return BWTS_OK;
+    char *p = nullptr;
+    BWTS_TRY(aux_reserve_slot(ctx, 4, align_up((size_t)n * 4, 256), &p));
+    sp.rank = (u32 *)p;
+    return BWTS_OK;
 }
 
 static int sort_space_alloc(bwts_ctx *ctx, u64 n, SortSpace *sp)
@@ -1111,10 +1122,10 @@ static int sort_space_alloc(bwts_ctx *ctx, u64 n, SortSpace *sp)
     sp->keys[1] = arena_array<u64>(ctx, n);
     sp->vals[0] = arena_array<u32>(ctx, n);
     sp->vals[1] = arena_array<u32>(ctx, n);
-    sp->rank = arena_array<u32>(ctx, n);
+    sp->rank = nullptr;            // ensure_rank()
     sp->tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
     sp->scan_temp = arena_alloc(ctx, scan_temp_bytes(n));
-    if (!sp->keys[0] || !sp->keys[1] || !sp->vals[0] || !sp->vals[1] || !sp->rank || !sp->tile_hist || !sp->scan_temp)
+    if (!sp->keys[0] || !sp->keys[1] || !sp->vals[0] || !sp->vals[1] || !sp->tile_hist || !sp->scan_temp)
         return BWTS_E_NOMEM;
     return BWTS_OK;
 }
@@ -2223,10 +2234,13 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         // flags and word prefixes (3 * n/8 bytes): in the carried-byte ping-pong buffers when there are any (free once the
         // sort is done), else in sp.rank, which is not needed before the rounds that follow
         const u64 words = (n + 63) / 64;
-        u64 *headw = (u64 *)sp.rank, *keepw = headw + words, *pre = keepw + words;
+        u64 *headw, *keepw, *pre;
         if (sp.carry_buf[0] && sp.carry_buf[1] && n >= 4096) {
             headw = (u64 *)sp.carry_buf[0]; keepw = headw + words; pre = (u64 *)sp.carry_buf[1];
             flag_heads = headw; flag_pre = pre;
+        } else {
+            BWTS_TRY(ensure_rank(ctx, sp, n));
+            headw = (u64 *)sp.rank; keepw = headw + words; pre = keepw + words;
         }
         u64 waves = (words + GF_WORDS - 1) / GF_WORDS;
         unsigned blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
@@ -2251,6 +2265,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         static const bool plain_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
         static const bool part_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "partition"); }();
         if (a > n / 32 && flag_heads && n >= (1ull << 22) && !plain_build && !part_build) {
+            BWTS_TRY(ensure_rank(ctx, sp, n));
             SpanGuard g(ctx, BWTS_K_RERANK, n, 28 * n);
             u64 *rk[2] = {sp.keys[res ^ 1], K0};
             u64 blocks = (n + 255) / 256; if (blocks > 16384) blocks = 16384;
@@ -2344,6 +2359,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             HIPC(hipGetLastError());
         } else {
             static const bool plain_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
+            BWTS_TRY(ensure_rank(ctx, sp, n));
             if (rank_early) {
                 // built before the tied list (see above)
             } else if (flag_heads && n >= (1ull << 22) && !plain_build) {
@@ -2486,7 +2502,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             if (rounds > 80) return BWTS_E_INTERNAL;
         }
     }
-    if (want_ranks && !rank_valid) BWTS_TRY(build_ranks(ctx, SA, n, a ? cur : none, a, sp.rank));
+    if (want_ranks && !rank_valid) { BWTS_TRY(ensure_rank(ctx, sp, n)); BWTS_TRY(build_ranks(ctx, SA, n, a ? cur : none, a, sp.rank)); }
     *sa_out = SA;
     *rounds_out = rounds;
     return BWTS_OK;
@@ -2577,8 +2593,9 @@ static int lyndon_general(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, u3
     BWTS_TRY(read_small(ctx, CNT_TOTAL, 1));
     const u64 k = ctx->h_small[CNT_TOTAL];
     if (k == 0 || k > n) return BWTS_E_INTERNAL;
-    u32 *dst = arena_array<u32>(ctx, k);
-    if (!dst) return BWTS_E_NOMEM;
+    char *fl = nullptr;
+    BWTS_TRY(aux_reserve_slot(ctx, 2, (size_t)k * 4, &fl));
+    u32 *dst = (u32 *)fl;
     HIPC(hipMemcpyAsync(dst, starts_tmp, k * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
     *d_fstart = dst;
     *k_out = k;
@@ -2923,9 +2940,9 @@ __global__ __launch_bounds__(256) void patch_ties_kernel(const u32 *__restrict__
 
 size_t forward_arena_bytes(u64 n)
 {
-    // candidate buffers + sort space + factor list (general path: up to n entries) + P + two carry buffers
-    return 8 * align_up(LYN_CAND_CAP * 8, 256) + sort_space_bytes(n) + align_up(n * 4, 256) + 3 * align_up(n, 256) + align_up(n / 256 + 64, 256) +
-           (1 << 16);
+    // candidate buffers + sort space + the round-0 flag words (packed passes; a sort on wide keys keeps the previous-symbol array
+    // and two carried-byte buffers in a side block instead, like the general path's factor list and the dense rank array)
+    return 8 * align_up(LYN_CAND_CAP * 8, 256) + sort_space_bytes(n) + 2 * align_up(n / 4 + 64, 256) + align_up(n / 256 + 64, 256) + (1 << 16);
 }
 
 int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
@@ -2958,9 +2975,11 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     // P[p] = T[cprev(p)] (mk_bwts_sa.c:172-188): a factor's head takes the factor's last byte.  With split keys the
     // byte already travels in the keys' c stream and no array is built.
     u8 *P = nullptr;
+    char *pc = nullptr;                 // side block of a sort on wide keys: P, then the two carried-byte buffers
+    const size_t n1 = align_up((size_t)n, 256);
     if (!sp.split_keys) {
-        P = arena_array<u8>(ctx, n);
-        if (!P) return BWTS_E_NOMEM;
+        BWTS_TRY(aux_reserve_slot(ctx, 3, carry ? 3 * n1 : n1, &pc));
+        P = (u8 *)pc;
         SpanGuard g(ctx, BWTS_K_OTHER, n, 2 * n);
         u64 blocks = (n / 16 + 255) / 256 + 1; if (blocks > 8192) blocks = 8192;
         prevsym_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(d_in, n, P);
@@ -2969,8 +2988,14 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     }
     if (carry) {
         sp.carry_src = P;
-        sp.carry_buf[0] = arena_array<u8>(ctx, n);
-        sp.carry_buf[1] = arena_array<u8>(ctx, n);
+        if (sp.split_keys) {
+            // the byte travels in the keys' c stream: these two only hold the round-0 flag words (2 x n/8 and n/8 bytes)
+            sp.carry_buf[0] = (u8 *)arena_alloc(ctx, (size_t)n / 4 + 64);
+            sp.carry_buf[1] = (u8 *)arena_alloc(ctx, (size_t)n / 8 + 64);
+        } else {
+            sp.carry_buf[0] = (u8 *)pc + n1;
+            sp.carry_buf[1] = (u8 *)pc + 2 * n1;
+        }
         sp.carry_out = d_out;
         if (!sp.carry_buf[0] || !sp.carry_buf[1]) return BWTS_E_NOMEM;
     }

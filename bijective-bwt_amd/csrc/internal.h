@@ -47,6 +47,7 @@ struct CopyPool {
 };
 
 #define STAGE_SLOTS 4
+#define BWTS_AUX_SLOTS 5
 
 #define SM_RX_SYNC 4090          // d_small word holding the two 32-bit counters of radix_column_scan_fused_kernel (zero between launches)
 
@@ -59,8 +60,11 @@ struct bwts_ctx {
     // device arena: one allocation, bump-allocated per call, grown between calls
     char  *arena;
     size_t arena_cap, arena_off;
-    char  *aux[2];         // side arenas sized on demand (forward: tied-set buffers; inverse: unreached-element lists, cycle sort)
-    size_t aux_cap[2];
+    // side arenas sized on demand.  0, 1: forward: tied-set buffers; inverse: unreached-element lists, cycle sort.  2: factor list of
+    // the general Lyndon path.  3: previous-symbol array + carried-byte buffers (rounds-0 sorts on wide keys).  4: dense rank array.
+    // (What the headline path does not touch is not allocated: the driver clears device memory it hands out, ~27 ms per GiB.)
+    char  *aux[BWTS_AUX_SLOTS];
+    size_t aux_cap[BWTS_AUX_SLOTS];
     size_t unv_hint;       // inverse: unreached elements seen by the previous call (sizes the first collection pass)
 
     // small pinned host block for read-backs, and a device mirror
@@ -89,6 +93,8 @@ struct bwts_ctx {
     std::vector<const void *> lds_granted;
 
     bwts_timings tm;
+    double host_ms[BWTS_H_COUNT];   // cumulative host-side costs (BWTS_H_*)
+    bool launched;                  // a kernel of this context has run (the code object is loaded)
 };
 
 #define HIPC(call)                                                        \
@@ -106,6 +112,7 @@ void bwts_trace_error(const char *file, int line, int rc);
     } while (0)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+double wall_ms(void);
 
 // ---- arena -------------------------------------------------------------------
 int  arena_reserve(bwts_ctx *ctx, size_t bytes);        // (re)allocates when too small; resets

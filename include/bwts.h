@@ -64,6 +64,16 @@ enum {
 
 #define BWTS_MAX_ROUND_STATS 40
 
+/* Host-side wall-clock costs a context has paid since it was created (what a one-shot CLI run spends outside kernels and copies). */
+enum {
+    BWTS_H_INIT = 0,        /* bwts_ctx_create: HIP runtime start-up, device, stream, small buffers */
+    BWTS_H_MODULE,          /* first kernel launch of the context: the code object is loaded then   */
+    BWTS_H_IO_ALLOC,        /* device-side copies of the caller's input / output (hipMalloc)         */
+    BWTS_H_STAGING_ALLOC,   /* pinned staging ring + copy workers                                    */
+    BWTS_H_ARENA_ALLOC,     /* device arenas (hipMalloc / hipFree when they grow)                    */
+    BWTS_H_COUNT
+};
+
 typedef struct bwts_kernel_stat {
     double   ms;         /* summed device time of this class in the last call            */
     uint64_t launches;   /* number of launches                                           */
@@ -85,6 +95,7 @@ typedef struct bwts_timings {
     uint64_t device_bytes;        /* device memory the context holds after the call (arenas, staging copies of in/out) */
     uint64_t round_active[BWTS_MAX_ROUND_STATS]; /* forward: elements still tied when sort round r+1 starts (r = 0: after round 0) */
     bwts_kernel_stat k[BWTS_K_COUNT];
+    double   host_ms[BWTS_H_COUNT]; /* cumulative since bwts_ctx_create (BWTS_H_*): start-up and allocation costs           */
 } bwts_timings;
 
 int  bwts_ctx_create(bwts_ctx **out, int device_id);
@@ -111,6 +122,7 @@ int bwts_inverse_device(bwts_ctx *ctx, const void *d_in, uint64_t n, void *d_out
 /* Statistics of the last forward/inverse call on this context (see bwts_set_timing for the per-kernel times). */
 int bwts_last_timings(bwts_ctx *ctx, bwts_timings *t);
 const char *bwts_kernel_class_name(int k);
+const char *bwts_host_cost_name(int h);
 
 const char *bwts_strerror(int code);
 int bwts_last_hip_error(bwts_ctx *ctx);          /* hipError_t of the last BWTS_E_HIP */

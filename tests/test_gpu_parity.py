@@ -462,6 +462,31 @@ def test_cli_end_to_end(tmp_path):
     assert r.returncode == 1 and r.stderr.decode().splitlines()[1] == "If outfile is not supplied, a unique file name is generated"
 
 
+def test_cli_in_place_and_failure_leaves_nothing(tmp_path):
+    """The output is opened when the first piece arrives (the reference transforms first and opens afterwards, mk_bwts_sa.c:47-60,
+    unbwts.c:62-89): a file can be transformed onto itself, and a transform that fails neither truncates an existing destination
+    nor leaves an auto-named file behind."""
+    x = O.generate("zipf", 300007, 23)
+    want = O.forward(x).tobytes()
+    f = tmp_path / "same.bin"
+    f.write_bytes(x.tobytes())
+    r = _run_cli([os.path.join(PKG, "mk_bwts"), str(f), str(f)])
+    assert r.returncode == 0 and f.read_bytes() == want
+    r = _run_cli([os.path.join(PKG, "unbwts"), str(f), str(f)])
+    assert r.returncode == 0 and f.read_bytes() == x.tobytes()
+    # a forced failure: the blocked 64-bit path without fallback refuses a^n (BWTS_E_RANGE, DESIGN.md section 8)
+    a_n = tmp_path / "an.bin"
+    a_n.write_bytes(b"a" * 100000)
+    dest = tmp_path / "precious.bwts"
+    dest.write_bytes(b"keep me")
+    env = dict(os.environ, BWTS_FORCE_WIDE="2")
+    r = _run_cli([os.path.join(PKG, "mk_bwts"), str(a_n), str(dest)], env=env)
+    assert r.returncode == 1 and b"transform failed" in r.stderr and dest.read_bytes() == b"keep me"
+    before = set(os.listdir(tmp_path))
+    r = _run_cli([os.path.join(PKG, "mk_bwts_new_algo"), str(a_n)], env=env)
+    assert r.returncode == 1 and set(os.listdir(tmp_path)) == before and b"Writing to" not in r.stdout
+
+
 def test_make_test_prints_match():
     """The reference's golden-file check (Makefile:30-33): mk_bwts_new_algo on testdata/testjunk, cmp, "Match"."""
     proc = subprocess.Popen(["make", "-C", PKG, "test"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
