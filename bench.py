@@ -147,27 +147,48 @@ def _per_kernel(a):
     return out
 
 
-def _pmc_traffic(kernel_label, per_elem, workload, log2n):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/).  The record
-    names the kernel, its bytes per element and the sha256 of the source file it was collected on: a kernel that has
-    changed since reports null instead of a stale figure."""
+def _pmc_traffic(kernel_prefix, workload, log2n, source_file, per_elem=None):
+    """HBM bytes of a kernel from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*.json, made by
+    tools/pmc_summary.py).  A record names the kernel, the workload and the sha256 of the source file the kernel lives in: a
+    kernel that has changed since reports null instead of a stale figure."""
     try:
+        cur = hashlib.sha256(open(os.path.join(ROOT, "bijective-bwt_amd", "csrc", source_file), "rb").read()).hexdigest()
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             if not (name.endswith(".json") and "pmc_traffic" in name):
                 continue
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             if not str(pm.get("workload", "zipf")).startswith(workload) or pm.get("log2n", 30) != log2n:
                 continue
-            if pm.get("kernel", "").split("<")[0] != kernel_label.split("<")[0] or pm.get("alg_bytes_per_element") != per_elem:
+            if pm.get("kernel", "").split("<")[0] != kernel_prefix.split("<")[0]:
                 continue
-            src = pm.get("source_sha256")
-            cur = hashlib.sha256(open(os.path.join(ROOT, "bijective-bwt_amd", "csrc", "radix.hip"), "rb").read()).hexdigest()
-            if cur != src:              # (records without a hash -- round 1 -- cannot vouch for today's kernel either)
+            if per_elem is not None and pm.get("alg_bytes_per_element") != per_elem:
                 continue
-            return pm["hbm_bytes_per_launch"], name
+            if pm.get("source_sha256") != cur:       # (records without a hash cannot vouch for today's kernel either)
+                continue
+            return pm.get("hbm_bytes_per_launch", pm.get("hbm_bytes_per_forward")), name
     except Exception:
         pass
     return None, None
+
+
+LINE_FILL_CEILING = 54e9       # random 128-byte line fills per second this chip sustains (tools/micro/random_read.hip, DESIGN.md section 4)
+
+
+def _roofline(kernel, st, traffic, traffic_src, note, per_forward=None):
+    """roofline object of one kernel class from its summed HIP-event time and algorithmic bytes (timed region)."""
+    ms = st.get("ms", 0.0)
+    launches = st.get("launches", 0)
+    achieved = st.get("alg_bytes", 0) / 1e9 / (ms / 1e3) if ms > 0 else 0.0
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+         "launches": launches, "timed": note}
+    if per_forward:
+        r["alg_bytes_per_forward"] = st.get("alg_bytes", 0) // per_forward
+        r["ms_per_forward"] = round(ms / per_forward, 3)
+    else:
+        r["alg_bytes_per_launch"] = st.get("alg_bytes", 0) // max(launches, 1)
+        r["ms_per_launch"] = round(ms / max(launches, 1), 4)
+    return r
 
 
 def _e2e(ctx, helper, d_in, d_out, n, workload):
@@ -373,7 +394,7 @@ def main(argv=None):
             20: "radix_scatter_packed_kernel<false,false,true> (8-bit LSD pass over packed streams: key-low 4 B + value 4 B + key-high|carried byte 2 B)",
             18: "radix_scatter_packed_kernel<false,false,false> (8-bit LSD pass over packed streams: key 4 B + value 4 B + carried byte 1 B)",
         }.get(per_elem, "radix_scatter2_kernel<512,16,4,true,false> (8-bit LSD pass, key 8 B + value 4 B + carried byte)")
-        traffic, traffic_src = _pmc_traffic(kernel_label, per_elem, args.workload, args.log2n)
+        traffic, traffic_src = _pmc_traffic(kernel_label, args.workload, args.log2n, "radix.hip", per_elem)
         size_label = "%d GiB" % (n >> 30) if n >= 1 << 30 and n % (1 << 30) == 0 else "%d MiB" % (n >> 20) if n >= 1 << 20 else "%d B" % n
         line = {
             "metric": "BWTS build MB/s on %s input (+ inverse MB/s); bit-exact round-trip" % size_label,
@@ -399,6 +420,20 @@ def main(argv=None):
                         "walk_ms_timed_region": round(m["inv_main"].get("walk", {}).get("ms", 0.0) / max(args.inverse_steps, 1), 3),
                         "kernels": _per_kernel(m["inv_agg"])},
         }
+        # second dominant kernel: the inverse's splitter walk -- bound by line fills, not bytes (one 128-byte fill per 4-byte LF read)
+        wk = m["inv_main"].get("walk")
+        if wk and wk.get("ms", 0) > 0:
+            wt, wsrc = _pmc_traffic("walk_record_kernel", args.workload, args.log2n, "inverse.hip")
+            rw = _roofline("walk_record_kernel<3,16> (one LF chase per splitter, symbols recorded in 64-byte blocks; 6 n algorithmic bytes: "
+                           "4 LF + 1 symbol + 1 output)", wk, wt, wsrc,
+                           "HIP events on the engine's stream inside the timed inverse region (%d calls)" % args.inverse_steps)
+            if wt:
+                fills = wt / 128.0 / (rw["ms_per_launch"] / 1e3)
+                rw["line_fills_per_s"] = round(fills / 1e9, 1)
+                rw["line_fill_ceiling_per_s"] = LINE_FILL_CEILING / 1e9
+                rw["line_fill_frac"] = round(fills / LINE_FILL_CEILING, 3)
+                rw["traffic_over_algorithmic"] = round(wt / max(rw["alg_bytes_per_launch"], 1), 1)
+            line["roofline_inverse"] = rw
         if selftest:
             line["data"] = "selftest (no transform executed)"
         if n_gpus == 1 and not selftest:
@@ -418,6 +453,14 @@ def main(argv=None):
                     "roundtrip_exact": bool(t["roundtrip"]), "rounds": ti["rounds"], "key_bits": ti["key_bits"], "factors": ti["factors"],
                     "round_active": ti.get("round_active"), "kernels": _per_kernel(t["agg"]),
                 }
+                rk = t["main"].get("round")
+                if rk and rk.get("ms", 0) > 0:
+                    # the text regime's dominant kernel: the group-local round over the chunked tied list (all launches of a forward)
+                    rt, rsrc = _pmc_traffic("chunk_round_kernel", "text", args.log2n, "chunk_rounds.h")
+                    line["text"]["roofline"] = _roofline(
+                        "chunk_round_kernel<true,3,true> + chunk_apply_moves_kernel (per list element and round: position + head in, three "
+                        "successor ranks gathered, position + head out, rank updated = 32 algorithmic bytes)", rk, rt, rsrc,
+                        "HIP events on the engine's stream inside the timed region of the text leg (2 forwards)", per_forward=2)
                 if not t["roundtrip"]:
                     bad = 1.0
             if not args.no_cpu_baseline:

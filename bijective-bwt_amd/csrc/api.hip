@@ -101,7 +101,7 @@ int span_begin(bwts_ctx *ctx, int cls, u64 elems, u64 alg_bytes)
     ctx->tm.k[cls].launches++;
     ctx->tm.k[cls].elems += elems;
     ctx->tm.k[cls].alg_bytes += alg_bytes;
-    if (ctx->timing < 2 && !(ctx->timing == 1 && (cls == BWTS_K_RADIX_SCATTER_MAIN || cls == BWTS_K_WALK))) return -1;
+    if (ctx->timing < 2 && !(ctx->timing == 1 && (cls == BWTS_K_RADIX_SCATTER_MAIN || cls == BWTS_K_WALK || cls == BWTS_K_ROUND))) return -1;
     TimedSpan sp;
     sp.cls = cls;
     sp.a = take_event(ctx);

@@ -629,7 +629,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             unsigned long long *res = (unsigned long long *)(slots + b * CH_SLOT_WORDS);
             hs[b] = h;
             if (nchunks) {
-                SpanGuard g(ctx, BWTS_K_ROUND, a_chunks, 32 * a_chunks);
+                SpanGuard g(ctx, BWTS_K_ROUND, 0, 0);          // (elements and bytes are added below, once the round's true size is known)
 #define CH_LAUNCH(NK, FS) chunk_round_kernel<CYCLIC, NK, FS><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, sp.rank, n, h, \
                                                                                                         d_fstart, k, prev, out, res)
                 const bool fsl = CYCLIC && k <= CH_FS;
@@ -696,8 +696,11 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             h = h > (1ull << 60) ? h : h << hshift;
         }
         CH_TRY(read_small(ctx, SM_CHSLOT, CH_SLOTS * CH_SLOT_WORDS));
-        for (int b = 0; b < B && !finished; b++) {
+        for (int b = 0; b < B; b++) {
             const u64 *r = ctx->h_small + SM_CHSLOT + b * CH_SLOT_WORDS;
+            // 32 algorithmic bytes per list element and round: position + head in, three successor ranks, position + head out, rank update
+            if (nchunks) { ctx->tm.k[BWTS_K_ROUND].elems += a_chunks; ctx->tm.k[BWTS_K_ROUND].alg_bytes += 32 * a_chunks; }
+            if (finished) continue;          // (a round enqueued behind the last one: it ran, over what was left, and changed nothing)
             rounds++;
             if (r[CHS_ERR]) {
                 if (round_trace) fprintf(stderr, "[chunks] chunk %llu of %u: group [%d, %d) plen %llu len %llu rp %llu slot %llu\n", (unsigned long long)r[5] - 1, nchunks,
@@ -738,9 +741,9 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             a_chunks = in_chunks + m_exit;
             const u64 left = a_chunks + m_big;
             if (CYCLIC && rounds - 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[rounds - 1] = left;
-            if (left == 0) { finished = true; break; }
+            if (left == 0) { finished = true; continue; }
             // no group split: the partition is stable under doubling -- what is left are groups of equal infinite words
-            if (CYCLIC && r[CHS_SPLIT] == 0) { finished = true; stable = true; break; }
+            if (CYCLIC && r[CHS_SPLIT] == 0) { finished = true; stable = true; continue; }
             if (!CYCLIC && hs[b] >= n) CH_FAIL("suffixes still tied at h >= n");      // suffixes are distinct; cannot happen
             if (rounds > 80) CH_FAIL("more than 80 rounds");
         }

@@ -128,7 +128,7 @@ const char *bwts_strerror(int code);
 int bwts_last_hip_error(bwts_ctx *ctx);          /* hipError_t of the last BWTS_E_HIP */
 
 /* Per-kernel HIP-event timing (bwts_timings.k[].ms) is off by default: ~400 event records per forward call cost
- * about 1 ms at 1 GiB.  level 0 = off; 1 = only the dominant kernel of each direction (BWTS_K_RADIX_SCATTER_MAIN, BWTS_K_WALK:
+ * about 1 ms at 1 GiB.  level 0 = off; 1 = only the dominant kernels (BWTS_K_RADIX_SCATTER_MAIN, BWTS_K_ROUND, BWTS_K_WALK:
  * a handful of events); 2 = every class.  Applies to the following calls of this context; the launch / element / byte
  * counters and total_ms are always filled.  A context created while BWTS_TIMINGS=1 is set starts at level 2
  * (the reference's -DSHOW_TIMINGS, mk_bwts_sa.c:13-22). */

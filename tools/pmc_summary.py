@@ -1,8 +1,10 @@
-"""Condenses two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) of bench.py into the two JSON files kept
-under profiles/: per-kernel means, and the HBM bytes per launch of the roofline kernel.
+"""Condenses two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) of bench.py into the JSON files kept under
+profiles/: per-kernel means, and the HBM bytes of the roofline kernels (bench.py reads those records, _pmc_traffic()).
 
-    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_dir> [round_tag]
+    python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out_dir> <round_tag> <workload> <log2n> <forwards> [<inverses>]
 
+<forwards> / <inverses> = forward / inverse transforms the profiled command ran (warm-up included): kernels that run several
+differently sized launches per transform (the rounds over the tied list) are reported per transform.
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are
 reported in KB, and FETCH_SIZE counts half of the coalesced read bytes on gfx950, hence x2.
 """
@@ -13,7 +15,14 @@ import json
 import os
 import sys
 
-ROOFLINE_KERNEL = "radix_scatter_packed_kernel<false, false, true>"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CORRECTION = "gfx950: FETCH_SIZE reports 1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE as is; units KB"
+# (record name, kernel-name prefixes summed together, source file, algorithmic bytes per element, per what)
+ROOFLINE = [
+    ("radix_scatter", ["radix_scatter_packed_kernel<false, false, true>"], "radix.hip", 20, "launch"),
+    ("walk", ["walk_record_kernel"], "inverse.hip", 6, "launch"),
+    ("text_round", ["chunk_round_kernel", "chunk_apply_moves_kernel"], "chunk_rounds.h", 32, "forward"),
+]
 
 
 def load(path):
@@ -23,35 +32,40 @@ def load(path):
     return acc
 
 
+def sha(source):
+    return hashlib.sha256(open(os.path.join(ROOT, "bijective-bwt_amd", "csrc", source), "rb").read()).hexdigest()
+
+
 def main():
-    fetch, write, out_dir = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
-    tag = sys.argv[4] if len(sys.argv) > 4 else "r02"
+    fetch, write, out_dir, tag, workload, log2n, forwards = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
+    inverses = int(sys.argv[8]) if len(sys.argv) > 8 else forwards
     allk = {}
     for name, acc in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
         for k, rows in acc.items():
             gmax = max(g for g, _ in rows)
-            big = [v for g, v in rows if g == gmax]          # the n-sized launches of this kernel
-            allk.setdefault(k[:120], {})[name] = {"launches_total": len(rows), "n_sized_launches": len(big),
-                                                  "mean_KB_n_sized": sum(big) / len(big)}
-    json.dump(allk, open(os.path.join(out_dir, tag + "_pmc_fetch_write_all_kernels.json"), "w"), indent=1)
-    key = [k for k in allk if k.startswith("void " + ROOFLINE_KERNEL) or k.startswith(ROOFLINE_KERNEL)]
-    if key:
-        f = allk[key[0]]["FETCH_SIZE"]["mean_KB_n_sized"]
-        w = allk[key[0]]["WRITE_SIZE"]["mean_KB_n_sized"]
-        json.dump({
-            "kernel": "radix_scatter_packed_kernel<false,false,true>",
-            "alg_bytes_per_element": 20,
-            "workload": "zipf(2^30, seed 1), n-sized launches of bench.py", "log2n": 30,
-            "source_sha256": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                              "bijective-bwt_amd", "csrc", "radix.hip"), "rb").read()).hexdigest(),
-            "FETCH_SIZE_KB_reported": f, "WRITE_SIZE_KB_reported": w,
-            "correction": "gfx950: FETCH_SIZE reports 1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE as is; units KB",
-            "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024),
-            "collected": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes",
-        }, open(os.path.join(out_dir, tag + "_pmc_traffic_radix_scatter.json"), "w"), indent=1)
-        print("roofline kernel: fetch KB", f, "write KB", w, "-> bytes/launch", int(2 * f * 1024 + w * 1024))
-    else:
-        print("roofline kernel not found in the counter files")
+            big = [v for g, v in rows if g == gmax]          # the largest launches of this kernel
+            allk.setdefault(k[:120], {})[name] = {"launches_total": len(rows), "largest_launches": len(big), "mean_KB_largest": sum(big) / len(big),
+                                                  "sum_KB": sum(v for _, v in rows)}
+    json.dump(allk, open(os.path.join(out_dir, "%s_pmc_fetch_write_all_kernels_%s_2p%d.json" % (tag, workload, log2n)), "w"), indent=1)
+    for rec, prefixes, source, per_elem, per in ROOFLINE:
+        keys = [k for k in allk if any(k.startswith("void " + p) or k.startswith(p) for p in prefixes)]
+        if not keys:
+            continue
+        out = {"kernel": prefixes[0] if len(prefixes) == 1 else " + ".join(prefixes), "alg_bytes_per_element": per_elem,
+               "workload": "%s(2^%d, seed 1)" % (workload, log2n), "log2n": log2n, "source_file": "csrc/" + source, "source_sha256": sha(source),
+               "correction": CORRECTION, "collected": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes"}
+        if per == "launch":
+            f = sum(allk[k]["FETCH_SIZE"]["mean_KB_largest"] for k in keys)
+            w = sum(allk[k]["WRITE_SIZE"]["mean_KB_largest"] for k in keys)
+            out.update({"FETCH_SIZE_KB_reported": f, "WRITE_SIZE_KB_reported": w, "hbm_bytes_per_launch": int(2 * f * 1024 + w * 1024)})
+        else:
+            div = forwards if rec != "walk" else inverses
+            f = sum(allk[k]["FETCH_SIZE"]["sum_KB"] for k in keys) / div
+            w = sum(allk[k]["WRITE_SIZE"]["sum_KB"] for k in keys) / div
+            out.update({"FETCH_SIZE_KB_reported_per_forward": f, "WRITE_SIZE_KB_reported_per_forward": w, "transforms_profiled": div,
+                        "hbm_bytes_per_forward": int(2 * f * 1024 + w * 1024)})
+        json.dump(out, open(os.path.join(out_dir, "%s_pmc_traffic_%s.json" % (tag, rec)), "w"), indent=1)
+        print(rec, {k: v for k, v in out.items() if "KB" in k or "bytes" in k})
 
 
 if __name__ == "__main__":
