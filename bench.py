@@ -227,6 +227,31 @@ def _e2e(ctx, helper, d_in, d_out, n, workload):
     res["host_buffers"] = "numpy arrays (malloc, unpinned); output allocated fresh for every call"
     del back
 
+    # a batch of independent inputs on this one GPU (BASELINE config 5's data flow per GPU): bwts_forward_batch overlaps item k+1's
+    # copy in and item k-1's copy out with item k's transform
+    if n <= (1 << 30):
+        items = 8
+        xs = [x]
+        tmp = ctx.alloc(n)
+        for sd in range(2, items + 1):
+            ctx.generate(workload, sd, n, tmp)
+            xs.append(tmp.download())
+        tmp.free()
+        ctx.forward_batch(xs[:2])                     # warm: the batch's own staging rings, workers and second pair of device buffers
+        t0 = time.perf_counter()
+        ys = ctx.forward_batch(xs)
+        bf = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        backs = ctx.inverse_batch(ys)
+        bi = time.perf_counter() - t0
+        res["batch_host_forward_MBps"] = round(items * n / 1e6 / bf, 1)
+        res["batch_host_inverse_MBps"] = round(items * n / 1e6 / bi, 1)
+        res["batch"] = {"items": items, "bytes_each": n, "forward_wall_ms": round(1e3 * bf, 1), "inverse_wall_ms": round(1e3 * bi, 1),
+                        "first_item_equals_device_path": bool(np.array_equal(ys[0], ymem)),
+                        "roundtrip_exact": bool(all(np.array_equal(b, xi) for b, xi in zip(backs, xs))),
+                        "inputs": "%s seeds 1..%d, unpinned numpy arrays; outputs allocated (untouched) inside the call" % (workload, items)}
+        del xs, ys, backs
+
     if helper is not None:
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
         td = tempfile.mkdtemp(prefix="bwts_bench_", dir=base)

@@ -36,6 +36,7 @@ EXPORTS = [
     "bwts_ctx_create", "bwts_ctx_destroy", "bwts_forward", "bwts_inverse", "bwts_forward_sink", "bwts_inverse_sink",
     "bwts_forward_device", "bwts_inverse_device", "bwts_last_timings", "bwts_kernel_class_name", "bwts_strerror",
     "bwts_last_hip_error", "bwts_set_timing", "bwts_host_alloc", "bwts_host_free", "bwts_host_cost_name",
+    "bwts_forward_batch", "bwts_inverse_batch",
 ]
 # ... and include/bwts_test.h (harness and unit-test hooks)
 TEST_EXPORTS = [
@@ -105,6 +106,8 @@ def lib():
         L.bwts_set_timing.argtypes = [vp, i32]
         L.bwts_host_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
         L.bwts_host_free.argtypes = [vp, vp]
+        for name in ("bwts_forward_batch", "bwts_inverse_batch"):
+            getattr(L, name).argtypes = [vp, i32, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(vp)]
         for name in ("bwts_forward_sink", "bwts_inverse_sink"):
             getattr(L, name).argtypes = [vp, vp, u64, SINK_FN, vp]
         L.bwts_generate_device.argtypes = [vp, i32, u64, u64, vp]
@@ -242,6 +245,23 @@ class Context:
 
     def host_free(self, ptr):
         self._check(lib().bwts_host_free(self._h, ptr))
+
+    def _batch(self, fn, arrays):
+        arrs = [_u8(a) for a in arrays]
+        outs = [np.empty_like(a) for a in arrs]
+        k = len(arrs)
+        ins_p = (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrs])
+        outs_p = (ctypes.c_void_p * k)(*[o.ctypes.data for o in outs])
+        ns = (ctypes.c_uint64 * k)(*[a.size for a in arrs])
+        self._check(fn(self._h, k, ins_p, ns, outs_p))
+        return outs
+
+    def forward_batch(self, arrays):
+        """bwts_forward_batch: the transforms of several inputs, copies overlapped with the neighbours' transforms."""
+        return self._batch(lib().bwts_forward_batch, arrays)
+
+    def inverse_batch(self, arrays):
+        return self._batch(lib().bwts_inverse_batch, arrays)
 
     def forward_into(self, a, out):
         """bwts_forward on caller-provided numpy buffers (no allocation inside the call)."""

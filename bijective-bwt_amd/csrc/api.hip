@@ -176,14 +176,17 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
     for (int i = 0; i < BWTS_AUX_SLOTS; i++) if (ctx->aux[i]) (void)hipFree(ctx->aux[i]);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
-    if (ctx->pool) { ctx->pool->shutdown(); delete ctx->pool; }
-    for (int i = 0; i < STAGE_SLOTS; i++) {
-        if (ctx->pinned[i]) (void)hipHostFree(ctx->pinned[i]);
-        if (ctx->slot_ev[i]) (void)hipEventDestroy(ctx->slot_ev[i]);
-        if (ctx->slot_ev2[i]) (void)hipEventDestroy(ctx->slot_ev2[i]);
+    for (Stager &sg : ctx->stg) {
+        if (sg.pool) { sg.pool->shutdown(); delete sg.pool; }
+        for (int i = 0; i < STAGE_SLOTS; i++) {
+            if (sg.pinned[i]) (void)hipHostFree(sg.pinned[i]);
+            if (sg.slot_ev[i]) (void)hipEventDestroy(sg.slot_ev[i]);
+            if (sg.slot_ev2[i]) (void)hipEventDestroy(sg.slot_ev2[i]);
+        }
+        if (sg.copy_stream) (void)hipStreamDestroy(sg.copy_stream);
+        if (sg.own_stream && sg.stream) (void)hipStreamDestroy(sg.stream);
     }
-    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-    for (int i = 0; i < 2; i++) if (ctx->d_io[i]) (void)hipFree(ctx->d_io[i]);
+    for (int i = 0; i < 4; i++) if (ctx->d_io[i]) (void)hipFree(ctx->d_io[i]);
     for (const auto &b : ctx->host_blocks) (void)hipHostFree(b.first);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -220,6 +223,7 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
     ctx->tm.total_ms = ms;
     ctx->tm.device_bytes = ctx->arena_cap + ctx->d_io_cap[0] + ctx->d_io_cap[1] + ctx->call_block_bytes;
     for (int i = 0; i < BWTS_AUX_SLOTS; i++) ctx->tm.device_bytes += ctx->aux_cap[i];
+    ctx->tm.device_bytes += ctx->d_io_cap[2] + ctx->d_io_cap[3];
     return BWTS_OK;
 }
 
@@ -345,10 +349,10 @@ static int copy_mode(const char *name)      // 0 = DMA engine (hipMemcpyAsync), 
     return -1;
 }
 
-static int pcie_copy(bwts_ctx *ctx, void *dst, const void *src, size_t len, bool use_kernel, hipMemcpyKind kind)
+static int pcie_copy(bwts_ctx *ctx, hipStream_t stream, void *dst, const void *src, size_t len, bool use_kernel, hipMemcpyKind kind)
 {
     if (!use_kernel || (((uintptr_t)dst | (uintptr_t)src) & 15)) {
-        HIPC(hipMemcpyAsync(dst, src, len, kind, ctx->stream));
+        HIPC(hipMemcpyAsync(dst, src, len, kind, stream));
         return BWTS_OK;
     }
     const u64 vecs = len / 16;
@@ -356,35 +360,38 @@ static int pcie_copy(bwts_ctx *ctx, void *dst, const void *src, size_t len, bool
     u64 blocks = (vecs + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    pcie_copy_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>((uint4 *)dst, (const uint4 *)src, vecs, (u8 *)dst + vecs * 16,
+    pcie_copy_kernel<<<dim3((unsigned)blocks), dim3(256), 0, stream>>>((uint4 *)dst, (const uint4 *)src, vecs, (u8 *)dst + vecs * 16,
                                                                             (const u8 *)src + vecs * 16, tail);
     HIPC(hipGetLastError());
     return BWTS_OK;
 }
 
-static int ensure_staging(bwts_ctx *ctx)
+static int ensure_staging(bwts_ctx *ctx, Stager &sg)
 {
     const double t0 = wall_ms();
-    const bool first = !ctx->pool;
+    const bool first = !sg.pool;
+    if (!sg.stream) {
+        if (&sg == &ctx->stg[0]) sg.stream = ctx->stream;
+        else { HIPC(hipStreamCreateWithFlags(&sg.stream, hipStreamNonBlocking)); sg.own_stream = true; }
+    }
     for (int i = 0; i < STAGE_SLOTS; i++) {
-        if (!ctx->pinned[i]) {
+        if (!sg.pinned[i]) {
             void *p = nullptr;
             if (hipHostMalloc(&p, STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
-            ctx->pinned[i] = (char *)p;
+            sg.pinned[i] = (char *)p;
         }
-        if (!ctx->slot_ev[i]) HIPC(hipEventCreateWithFlags(&ctx->slot_ev[i], hipEventDisableTiming));
-        if (!ctx->slot_ev2[i]) HIPC(hipEventCreateWithFlags(&ctx->slot_ev2[i], hipEventDisableTiming));
+        if (!sg.slot_ev[i]) HIPC(hipEventCreateWithFlags(&sg.slot_ev[i], hipEventDisableTiming));
+        if (!sg.slot_ev2[i]) HIPC(hipEventCreateWithFlags(&sg.slot_ev2[i], hipEventDisableTiming));
     }
-    if (!ctx->copy_stream) HIPC(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    ctx->pinned_cap = STAGE_CHUNK;
-    if (!ctx->pool) {
+    if (!sg.copy_stream) HIPC(hipStreamCreateWithFlags(&sg.copy_stream, hipStreamNonBlocking));
+    if (!sg.pool) {
         int threads = 6;                                   // BWTS_COPY_THREADS: 1 = the calling thread alone
         if (const char *e = getenv("BWTS_COPY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) threads = v; }
         const unsigned hw = std::thread::hardware_concurrency();
         if (hw && (unsigned)threads > hw) threads = (int)hw;
-        ctx->pool = new (std::nothrow) CopyPool();
-        if (!ctx->pool) return BWTS_E_NOMEM;
-        ctx->pool->start(threads);
+        sg.pool = new (std::nothrow) CopyPool();
+        if (!sg.pool) return BWTS_E_NOMEM;
+        sg.pool->start(threads);
     }
     if (first) ctx->host_ms[BWTS_H_STAGING_ALLOC] += wall_ms() - t0;
     return BWTS_OK;
@@ -397,41 +404,44 @@ static bool is_pinned_block(const bwts_ctx *ctx, const void *p, u64 n)
     return false;
 }
 
-static int staged_h2d(bwts_ctx *ctx, u8 *d_dst, const u8 *h_src, u64 n)
+static int staged_h2d(bwts_ctx *ctx, Stager &sg, u8 *d_dst, const u8 *h_src, u64 n)
 {
     static const int mode = copy_mode("BWTS_H2D");
     const bool by_kernel = mode == 1;
+    BWTS_TRY(ensure_staging(ctx, sg));
     if (is_pinned_block(ctx, h_src, n)) {
-        BWTS_TRY(pcie_copy(ctx, d_dst, h_src, n, by_kernel, hipMemcpyHostToDevice));
-        HIPC(hipStreamSynchronize(ctx->stream));
+        BWTS_TRY(pcie_copy(ctx, sg.stream, d_dst, h_src, n, by_kernel, hipMemcpyHostToDevice));
+        HIPC(hipStreamSynchronize(sg.stream));
         return BWTS_OK;
     }
-    BWTS_TRY(ensure_staging(ctx));
     u64 off = 0;
     for (u64 c = 0; off < n; c++) {
         const int slot = (int)(c % STAGE_SLOTS);
         const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
-        if (c >= STAGE_SLOTS) HIPC(hipEventSynchronize(ctx->slot_ev[slot]));       // the slot's previous DMA has read it
-        ctx->pool->copy(ctx->pinned[slot], h_src + off, len);
-        BWTS_TRY(pcie_copy(ctx, d_dst + off, ctx->pinned[slot], len, by_kernel, hipMemcpyHostToDevice));
-        HIPC(hipEventRecord(ctx->slot_ev[slot], ctx->stream));
+        if (c >= STAGE_SLOTS) HIPC(hipEventSynchronize(sg.slot_ev[slot]));       // the slot's previous DMA has read it
+        sg.pool->copy(sg.pinned[slot], h_src + off, len);
+        BWTS_TRY(pcie_copy(ctx, sg.stream, d_dst + off, sg.pinned[slot], len, by_kernel, hipMemcpyHostToDevice));
+        HIPC(hipEventRecord(sg.slot_ev[slot], sg.stream));
         off += len;
     }
-    HIPC(hipStreamSynchronize(ctx->stream));
+    HIPC(hipStreamSynchronize(sg.stream));
     return BWTS_OK;
 }
 
 // the result leaves in consecutive pieces: to h_dst (copy workers), or to the caller's sink straight from the staging slot
-static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n, bwts_sink_fn sink, void *user)
+static int staged_d2h(bwts_ctx *ctx, Stager &sg, u8 *h_dst, const u8 *d_src, u64 n, bwts_sink_fn sink, void *user)
 {
     static const int mode = copy_mode("BWTS_D2H");
-    const bool by_kernel = mode != 0;              // default: copy kernel
+    // default: the copy kernel for a single call (54 GB/s against the DMA engine's 29), the DMA engine inside a batch: there the
+    // copy runs beside the next item's transform, whose kernels a copy kernel slows down by half (8 x 1 GiB: 18.0 GB/s with the
+    // kernel, 24.4 GB/s with the engine -- the transform is the pipeline's slowest stage either way)
+    const bool by_kernel = mode == 1 || (mode == -1 && &sg == &ctx->stg[0]);
+    BWTS_TRY(ensure_staging(ctx, sg));
     if (!sink && is_pinned_block(ctx, h_dst, n)) {
-        BWTS_TRY(pcie_copy(ctx, h_dst, d_src, n, by_kernel, hipMemcpyDeviceToHost));
-        HIPC(hipStreamSynchronize(ctx->stream));
+        BWTS_TRY(pcie_copy(ctx, sg.stream, h_dst, d_src, n, by_kernel, hipMemcpyDeviceToHost));
+        HIPC(hipStreamSynchronize(sg.stream));
         return BWTS_OK;
     }
-    BWTS_TRY(ensure_staging(ctx));
     // a chunk's first part is moved by the copy kernel, the rest by the DMA engine on the second queue: the two paths
     // add up on the link (BWTS_D2H_SPLIT = percent moved by the kernel)
     static const int kernel_pct = [] { const char *e = getenv("BWTS_D2H_SPLIT"); int v = e ? atoi(e) : 100; return v < 0 ? 0 : v > 100 ? 100 : v; }();
@@ -442,10 +452,10 @@ static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n, bwts_sin
         const int slot = (int)(c % STAGE_SLOTS);
         size_t klen = by_kernel ? (len * (size_t)kernel_pct / 100) & ~(size_t)4095 : 0;
         if (by_kernel && kernel_pct == 100) klen = len;
-        if (klen) BWTS_TRY(pcie_copy(ctx, ctx->pinned[slot], d_src + off, klen, true, hipMemcpyDeviceToHost));
-        HIPC(hipEventRecord(ctx->slot_ev[slot], ctx->stream));
-        if (klen < len) HIPC(hipMemcpyAsync(ctx->pinned[slot] + klen, d_src + off + klen, len - klen, hipMemcpyDeviceToHost, ctx->copy_stream));
-        HIPC(hipEventRecord(ctx->slot_ev2[slot], ctx->copy_stream));
+        if (klen) BWTS_TRY(pcie_copy(ctx, sg.stream, sg.pinned[slot], d_src + off, klen, true, hipMemcpyDeviceToHost));
+        HIPC(hipEventRecord(sg.slot_ev[slot], sg.stream));
+        if (klen < len) HIPC(hipMemcpyAsync(sg.pinned[slot] + klen, d_src + off + klen, len - klen, hipMemcpyDeviceToHost, sg.copy_stream));
+        HIPC(hipEventRecord(sg.slot_ev2[slot], sg.copy_stream));
         return BWTS_OK;
     };
     for (u64 c = 0; c < chunks && c < STAGE_SLOTS; c++) BWTS_TRY(issue(c));
@@ -454,22 +464,24 @@ static int staged_d2h(bwts_ctx *ctx, u8 *h_dst, const u8 *d_src, u64 n, bwts_sin
         const u64 off = c * STAGE_CHUNK;
         const size_t len = n - off < STAGE_CHUNK ? (size_t)(n - off) : STAGE_CHUNK;
         const int slot = (int)(c % STAGE_SLOTS);
-        if (hipEventSynchronize(ctx->slot_ev[slot]) != hipSuccess || hipEventSynchronize(ctx->slot_ev2[slot]) != hipSuccess) { rc = BWTS_E_HIP; break; }
-        if (sink) { if (sink(user, (const uint8_t *)ctx->pinned[slot], len) != 0) { rc = BWTS_E_SINK; break; } }
-        else ctx->pool->copy(h_dst + off, ctx->pinned[slot], len);
+        if (hipEventSynchronize(sg.slot_ev[slot]) != hipSuccess || hipEventSynchronize(sg.slot_ev2[slot]) != hipSuccess) { rc = BWTS_E_HIP; break; }
+        if (sink) { if (sink(user, (const uint8_t *)sg.pinned[slot], len) != 0) { rc = BWTS_E_SINK; break; } }
+        else sg.pool->copy(h_dst + off, sg.pinned[slot], len);
         if (c + STAGE_SLOTS < chunks && (rc = issue(c + STAGE_SLOTS)) != BWTS_OK) break;
     }
-    if (hipStreamSynchronize(ctx->copy_stream) != hipSuccess && rc == BWTS_OK) rc = BWTS_E_HIP;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == BWTS_OK) rc = BWTS_E_HIP;
+    if (hipStreamSynchronize(sg.copy_stream) != hipSuccess && rc == BWTS_OK) rc = BWTS_E_HIP;
+    if (hipStreamSynchronize(sg.stream) != hipSuccess && rc == BWTS_OK) rc = BWTS_E_HIP;
     return rc;
 }
 
 
-// device-side copies of the caller's input and output stay with the context (grown, never shrunk)
-static int ensure_io(bwts_ctx *ctx, u64 n)
+// device-side copies of the caller's input and output stay with the context (grown, never shrunk): d_io[0], d_io[1] inputs,
+// d_io[2], d_io[3] outputs; the single calls use the first of each pair
+static int ensure_io(bwts_ctx *ctx, u64 n, bool pairs)
 {
     const double t0 = wall_ms();
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 4; i++) {
+        if (!pairs && (i & 1)) continue;
         if (ctx->d_io_cap[i] >= n) continue;
         if (ctx->d_io[i]) { HIPC(hipFree(ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
         void *p = nullptr;
@@ -482,35 +494,141 @@ static int ensure_io(bwts_ctx *ctx, u64 n)
     return BWTS_OK;
 }
 
+static size_t arena_hint(device_impl_fn fn, u64 n)
+{
+    return n <= 0x100000000ull ? (fn == forward_device_impl ? forward_arena_bytes(n) : inverse_arena_bytes(n)) : 0;
+}
+
 static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_t n, uint8_t *out, bwts_sink_fn sink, void *user)
 {
     if (!ctx || !in || (!out && !sink) || n == 0) return BWTS_E_ARG;
     HIPC(hipSetDevice(ctx->device));
-    BWTS_TRY(ensure_io(ctx, n));
-    // a context's first call allocates its arena, which costs as long as the whole input copy (the driver clears what it hands
+    BWTS_TRY(ensure_io(ctx, n, false));
+    Stager &sg = ctx->stg[0];
+    // a context's first call allocates its arena, which can cost as long as the whole input copy (the driver clears what it hands
     // out): a helper thread does it while this one stages the input
-    const size_t want = n <= 0x100000000ull ? (fn == forward_device_impl ? forward_arena_bytes(n) : inverse_arena_bytes(n)) : 0;
+    const size_t want = arena_hint(fn, n);
     std::thread reserve;
     int reserve_rc = BWTS_OK;
     if (want > ctx->arena_cap)
         reserve = std::thread([ctx, want, &reserve_rc] { if (hipSetDevice(ctx->device) == hipSuccess) reserve_rc = arena_reserve(ctx, want); });
     double t0 = wall_ms();
-    const int h2d_rc = staged_h2d(ctx, ctx->d_io[0], in, n);
+    const int h2d_rc = staged_h2d(ctx, sg, ctx->d_io[0], in, n);
     if (reserve.joinable()) reserve.join();
     BWTS_TRY(h2d_rc);
     if (reserve_rc != BWTS_OK && reserve_rc != BWTS_E_NOMEM) return reserve_rc;       // (out of memory: the transform's own reservation reports it)
     const double h2d = wall_ms() - t0;
     // the caller's output buffer is usually fresh: its page faults are taken by the copy workers during the transform
-    const bool touch = !sink && !is_pinned_block(ctx, out, n) && ensure_staging(ctx) == BWTS_OK;
-    if (touch) ctx->pool->touch_async(out, n);
-    const int rcd = run_device(ctx, fn, ctx->d_io[0], n, ctx->d_io[1]);
-    if (touch) ctx->pool->wait();
+    const bool touch = !sink && !is_pinned_block(ctx, out, n) && ensure_staging(ctx, sg) == BWTS_OK;
+    if (touch) sg.pool->touch_async(out, n);
+    const int rcd = run_device(ctx, fn, ctx->d_io[0], n, ctx->d_io[2]);
+    if (touch) sg.pool->wait();
     BWTS_TRY(rcd);
     t0 = wall_ms();
-    const int rc = staged_d2h(ctx, out, ctx->d_io[1], n, sink, user);
+    const int rc = staged_d2h(ctx, sg, out, ctx->d_io[2], n, sink, user);
     ctx->tm.d2h_ms = wall_ms() - t0;
     ctx->tm.h2d_ms = h2d;
     return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// batches of independent inputs on one context (BASELINE config 5's data flow per GPU): a three-stage pipeline
+// ------------------------------------------------------------------------------------
+// While item k is transformed (the calling thread, the context's stream), item k+1 is staged to the device by one helper thread
+// (stg[1], its own queue and copy workers) and item k-1 is drained to the caller's buffer by another (stg[2]).  Two device buffers
+// per direction; an item's input buffer is free again when its transform is done, its output buffer when it has been drained.
+// Every item goes through exactly the code of the single calls, so the bytes are the same.
+struct BatchState {
+    std::mutex mu;
+    std::condition_variable cv;
+    int staged = -1, transformed = -1, drained = -1;     // highest item index that has passed each stage
+    int error = BWTS_OK;
+};
+
+static int run_batch(bwts_ctx *ctx, device_impl_fn fn, int count, const uint8_t *const *ins, const uint64_t *ns, uint8_t *const *outs)
+{
+    if (!ctx || count < 0 || (count && (!ins || !ns || !outs))) return BWTS_E_ARG;
+    u64 nmax = 0;
+    for (int k = 0; k < count; k++) {
+        if (!ins[k] || !outs[k] || ns[k] == 0) return BWTS_E_ARG;
+        if (ns[k] > nmax) nmax = ns[k];
+    }
+    if (count == 0) return BWTS_OK;
+    HIPC(hipSetDevice(ctx->device));
+    BWTS_TRY(ensure_io(ctx, nmax, true));
+    BWTS_TRY(ensure_staging(ctx, ctx->stg[1]));
+    BWTS_TRY(ensure_staging(ctx, ctx->stg[2]));
+    BWTS_TRY(arena_reserve(ctx, arena_hint(fn, nmax) > ctx->arena_cap ? arena_hint(fn, nmax) : ctx->arena_cap));
+    BatchState st;
+    double busy[3] = {0, 0, 0};          // time the three stages spent working (BWTS_BATCH_TRACE=1 prints them)
+    auto fail = [&st](int rc) { std::lock_guard<std::mutex> lk(st.mu); if (st.error == BWTS_OK) st.error = rc; st.cv.notify_all(); };
+    const double t_begin = wall_ms();
+    std::thread feeder([&] {
+        if (hipSetDevice(ctx->device) != hipSuccess) { fail(BWTS_E_HIP); return; }
+        for (int k = 0; k < count; k++) {
+            {   // input buffer k % 2 is free once item k - 2 has been transformed
+                std::unique_lock<std::mutex> lk(st.mu);
+                st.cv.wait(lk, [&] { return st.error != BWTS_OK || st.transformed >= k - 2; });
+                if (st.error != BWTS_OK) return;
+            }
+            const double t0 = wall_ms();
+            const int rc = staged_h2d(ctx, ctx->stg[1], ctx->d_io[k & 1], ins[k], ns[k]);
+            busy[0] += wall_ms() - t0;
+            if (rc != BWTS_OK) { fail(rc); return; }
+            { std::lock_guard<std::mutex> lk(st.mu); st.staged = k; }
+            st.cv.notify_all();
+        }
+    });
+    std::thread drainer([&] {
+        if (hipSetDevice(ctx->device) != hipSuccess) { fail(BWTS_E_HIP); return; }
+        for (int k = 0; k < count; k++) {
+            // the caller's buffer is usually fresh: fault its pages in while the item is still being transformed
+            const bool touch = !is_pinned_block(ctx, outs[k], ns[k]);
+            if (touch) ctx->stg[2].pool->touch_async(outs[k], ns[k]);
+            {
+                std::unique_lock<std::mutex> lk(st.mu);
+                st.cv.wait(lk, [&] { return st.error != BWTS_OK || st.transformed >= k; });
+                if (touch) { lk.unlock(); ctx->stg[2].pool->wait(); lk.lock(); }
+                if (st.error != BWTS_OK) return;
+            }
+            const double t0 = wall_ms();
+            const int rc = staged_d2h(ctx, ctx->stg[2], outs[k], ctx->d_io[2 + (k & 1)], ns[k], nullptr, nullptr);
+            busy[2] += wall_ms() - t0;
+            if (rc != BWTS_OK) { fail(rc); return; }
+            { std::lock_guard<std::mutex> lk(st.mu); st.drained = k; }
+            st.cv.notify_all();
+        }
+    });
+    for (int k = 0; k < count; k++) {
+        {   // input k on the device, output buffer k % 2 drained of item k - 2
+            std::unique_lock<std::mutex> lk(st.mu);
+            st.cv.wait(lk, [&] { return st.error != BWTS_OK || (st.staged >= k && st.drained >= k - 2); });
+            if (st.error != BWTS_OK) break;
+        }
+        const double t0 = wall_ms();
+        const int rc = run_device(ctx, fn, ctx->d_io[k & 1], ns[k], ctx->d_io[2 + (k & 1)]);
+        busy[1] += wall_ms() - t0;
+        if (rc != BWTS_OK) { fail(rc); break; }
+        { std::lock_guard<std::mutex> lk(st.mu); st.transformed = k; }
+        st.cv.notify_all();
+    }
+    feeder.join();
+    drainer.join();
+    if (const char *e = getenv("BWTS_BATCH_TRACE"))
+        if (e[0] == '1') fprintf(stderr, "[batch] %d items, wall %.1f ms; busy: copy in %.1f, transform %.1f, copy out %.1f ms\n", count, wall_ms() - t_begin, busy[0], busy[1], busy[2]);
+    ctx->tm.h2d_ms = 0;
+    ctx->tm.d2h_ms = wall_ms() - t_begin;        // (batch: wall time of the whole pipeline; total_ms is the last item's transform)
+    return st.error;
+}
+
+extern "C" int bwts_forward_batch(bwts_ctx *ctx, int count, const uint8_t *const *ins, const uint64_t *ns, uint8_t *const *outs)
+{
+    return run_batch(ctx, forward_device_impl, count, ins, ns, outs);
+}
+
+extern "C" int bwts_inverse_batch(bwts_ctx *ctx, int count, const uint8_t *const *ins, const uint64_t *ns, uint8_t *const *outs)
+{
+    return run_batch(ctx, inverse_device_impl, count, ins, ns, outs);
 }
 
 extern "C" int bwts_forward(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out)

@@ -51,6 +51,15 @@ struct CopyPool {
 
 #define SM_RX_SYNC 4090          // d_small word holding the two 32-bit counters of radix_column_scan_fused_kernel (zero between launches)
 
+struct Stager {
+    hipStream_t stream;             // the queue its copies (and copy kernels) are issued on
+    bool own_stream;
+    char *pinned[STAGE_SLOTS];
+    hipEvent_t slot_ev[STAGE_SLOTS], slot_ev2[STAGE_SLOTS];
+    hipStream_t copy_stream;        // second queue: part of a device-to-host chunk goes through the DMA engine while a kernel moves the rest
+    CopyPool *pool;
+};
+
 struct bwts_ctx {
     int device;
     hipStream_t stream;
@@ -71,15 +80,13 @@ struct bwts_ctx {
     u64 *h_small;          // 4096 u64
     u64 *d_small;          // 4096 u64
 
-    // host-buffer entry points: pinned staging ring with one event per slot, copy workers, device-side in/out buffers
-    // that stay with the context, and the pinned blocks handed out by bwts_host_alloc
-    char  *pinned[STAGE_SLOTS];
-    hipEvent_t slot_ev[STAGE_SLOTS], slot_ev2[STAGE_SLOTS];
-    hipStream_t copy_stream;        // second queue: part of a device-to-host chunk goes through the DMA engine while a kernel moves the rest
-    size_t pinned_cap;
-    CopyPool *pool;
-    u8    *d_io[2];
-    size_t d_io_cap[2];
+    // host-buffer entry points: staging (a ring of pinned slots with one event each, copy workers, a queue of its own), device-side
+    // in/out buffers that stay with the context, and the pinned blocks handed out by bwts_host_alloc.  stg[0] serves the single
+    // calls on the context's own stream; the batch entry points move the neighbouring items' data on stg[1] (in) and stg[2] (out)
+    // while the current item is transformed, between two pairs of device buffers (d_io[0..1] in, d_io[2..3] out).
+    Stager stg[3];
+    u8    *d_io[4];
+    size_t d_io_cap[4];
     std::vector<std::pair<char *, size_t>> host_blocks;
 
     // event pool + spans of the current call

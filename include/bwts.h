@@ -113,6 +113,14 @@ typedef int (*bwts_sink_fn)(void *user, const uint8_t *data, uint64_t len);
 int bwts_forward_sink(bwts_ctx *ctx, const uint8_t *in, uint64_t n, bwts_sink_fn sink, void *user);
 int bwts_inverse_sink(bwts_ctx *ctx, const uint8_t *in, uint64_t n, bwts_sink_fn sink, void *user);
 
+/* Several independent inputs, one after another on this context (what a GPU does in a batched job: BASELINE config 5 puts one such
+ * stream of files on every GPU), with the copies overlapped with the transforms: while item k is transformed, item k + 1 is on its
+ * way to the device and item k - 1 on its way back.  ins[k] / outs[k]: caller-owned host memory of ns[k] bytes each (unpinned is
+ * fine); the bytes are those of count single calls.  Stops at the first error.  Afterwards bwts_last_timings() describes the
+ * last item's transform, with d2h_ms = wall time of the whole batch. */
+int bwts_forward_batch(bwts_ctx *ctx, int count, const uint8_t *const *ins, const uint64_t *ns, uint8_t *const *outs);
+int bwts_inverse_batch(bwts_ctx *ctx, int count, const uint8_t *const *ins, const uint64_t *ns, uint8_t *const *outs);
+
 /* Device-buffer entry points: d_in/d_out are device pointers on the context's
  * GPU (d_out may not alias d_in).  Synchronous: the call returns after the
  * result is complete in d_out. */

@@ -533,6 +533,30 @@ def test_host_path_pinned_blocks(ctx):
         ctx.host_free(pb)
 
 
+def test_batch_equals_single_calls(ctx, pkg):
+    """bwts_forward_batch / bwts_inverse_batch (copies of the neighbouring items overlapped with the transform): the bytes of the
+    single calls, for items of very different sizes; a bad item is refused before anything runs."""
+    xs = [O.generate("zipf", (3 << 20) + 1, 31), np.frombuffer(b"b", dtype=np.uint8), O.generate("uniform256", (9 << 20) + 5, 32),
+          O.generate("text", 5 << 20, 33), np.frombuffer(b"mississippi banana", dtype=np.uint8), O.generate("dna", 1 << 20, 34),
+          O.generate("zipf", 17 << 20, 35)]
+    ys = ctx.forward_batch(xs)
+    for x, y in zip(xs, ys):
+        assert np.array_equal(y, O.forward(x))
+    backs = ctx.inverse_batch(ys)
+    for x, b in zip(xs, backs):
+        assert np.array_equal(b, x)
+    assert ctx.forward_batch([]) == []
+    import ctypes
+    bad_in = (ctypes.c_void_p * 2)(xs[0].ctypes.data, None)
+    outs = [np.empty_like(xs[0]), np.empty_like(xs[0])]
+    bad_out = (ctypes.c_void_p * 2)(outs[0].ctypes.data, outs[1].ctypes.data)
+    ns = (ctypes.c_uint64 * 2)(xs[0].size, 5)
+    assert pkg.lib().bwts_forward_batch(ctx._h, 2, bad_in, ns, bad_out) == -1
+    ns0 = (ctypes.c_uint64 * 2)(xs[0].size, 0)
+    ok_in = (ctypes.c_void_p * 2)(xs[0].ctypes.data, xs[0].ctypes.data)
+    assert pkg.lib().bwts_forward_batch(ctx._h, 2, ok_in, ns0, bad_out) == -1
+
+
 def test_sink_error_aborts(ctx, pkg):
     import ctypes
     x = O.generate("zipf", 100000, 2)
