@@ -22,6 +22,40 @@ void bwts_trace_error(const char *file, int line, int rc)
 }
 
 // ------------------------------------------------------------------------------------
+// environment knobs
+// ------------------------------------------------------------------------------------
+// Read once per context.  Always: diagnostics and the staging tuning below.  Everything else selects alternate code paths that exist
+// for the test suite (tests/test_gpu_parity.py::test_alternate_paths) and for A/B timing sessions: those are only looked at when
+// BWTS_TEST_KNOBS=1 is set, so a process that merely inherits a stray BWTS_* variable runs the product paths.
+static const char *const kPublicKnobs[] = {"BWTS_TIMINGS", "BWTS_TRACE_ERRORS", "BWTS_ROUND_TRACE", "BWTS_INV_TRACE", "BWTS_BATCH_TRACE",
+                                           "BWTS_COPY_THREADS", "BWTS_H2D", "BWTS_D2H", "BWTS_D2H_SPLIT"};
+extern char **environ;
+int radix_config_count(void);
+
+static void read_knobs(bwts_ctx *ctx)
+{
+    const char *gate = getenv("BWTS_TEST_KNOBS");
+    const bool all = gate && gate[0] == '1';
+    for (char **e = environ; e && *e; e++) {
+        if (strncmp(*e, "BWTS_", 5) != 0) continue;
+        const char *eq = strchr(*e, '=');
+        if (!eq) continue;
+        std::string name(*e, (size_t)(eq - *e));
+        bool pub = false;
+        for (const char *k : kPublicKnobs) if (name == k) pub = true;
+        if (pub || all) ctx->knobs.emplace_back(name, std::string(eq + 1));
+    }
+    ctx->rx_config = 0;
+    if (const char *v = bwts_knob(ctx, "BWTS_RX_CONFIG")) { const int c = atoi(v); if (c >= 0 && c < radix_config_count()) ctx->rx_config = c; }
+}
+
+const char *bwts_knob(const bwts_ctx *ctx, const char *name)
+{
+    for (const auto &kv : ctx->knobs) if (kv.first == name) return kv.second.c_str();
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------
 // arenas
 // ------------------------------------------------------------------------------------
 int arena_reserve(bwts_ctx *ctx, size_t bytes)
@@ -149,7 +183,8 @@ extern "C" int bwts_ctx_create(bwts_ctx **out, int device_id)
     bwts_ctx *ctx = new (std::nothrow) bwts_ctx();
     if (!ctx) return BWTS_E_NOMEM;
     ctx->device = device_id;
-    { const char *e = getenv("BWTS_TIMINGS"); ctx->timing = (e && e[0] == '1') ? 2 : 0; }
+    read_knobs(ctx);
+    { const char *e = bwts_knob(ctx, "BWTS_TIMINGS"); ctx->timing = (e && e[0] == '1') ? 2 : 0; }
     if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return BWTS_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BWTS_E_HIP; }
     void *p = nullptr;
@@ -341,9 +376,9 @@ __global__ __launch_bounds__(256) void pcie_copy_kernel(uint4 *__restrict__ dst,
     if (blockIdx.x == 0 && threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 
-static int copy_mode(const char *name)      // 0 = DMA engine (hipMemcpyAsync), 1 = copy kernel
+static int copy_mode(const bwts_ctx *ctx, const char *name)      // 0 = DMA engine (hipMemcpyAsync), 1 = copy kernel
 {
-    const char *e = getenv(name);
+    const char *e = bwts_knob(ctx, name);
     if (e && !strcmp(e, "dma")) return 0;
     if (e && !strcmp(e, "kernel")) return 1;
     return -1;
@@ -386,7 +421,7 @@ static int ensure_staging(bwts_ctx *ctx, Stager &sg)
     if (!sg.copy_stream) HIPC(hipStreamCreateWithFlags(&sg.copy_stream, hipStreamNonBlocking));
     if (!sg.pool) {
         int threads = 6;                                   // BWTS_COPY_THREADS: 1 = the calling thread alone
-        if (const char *e = getenv("BWTS_COPY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) threads = v; }
+        if (const char *e = bwts_knob(ctx, "BWTS_COPY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) threads = v; }
         const unsigned hw = std::thread::hardware_concurrency();
         if (hw && (unsigned)threads > hw) threads = (int)hw;
         sg.pool = new (std::nothrow) CopyPool();
@@ -406,7 +441,7 @@ static bool is_pinned_block(const bwts_ctx *ctx, const void *p, u64 n)
 
 static int staged_h2d(bwts_ctx *ctx, Stager &sg, u8 *d_dst, const u8 *h_src, u64 n)
 {
-    static const int mode = copy_mode("BWTS_H2D");
+    const int mode = copy_mode(ctx, "BWTS_H2D");
     const bool by_kernel = mode == 1;
     BWTS_TRY(ensure_staging(ctx, sg));
     if (is_pinned_block(ctx, h_src, n)) {
@@ -431,7 +466,7 @@ static int staged_h2d(bwts_ctx *ctx, Stager &sg, u8 *d_dst, const u8 *h_src, u64
 // the result leaves in consecutive pieces: to h_dst (copy workers), or to the caller's sink straight from the staging slot
 static int staged_d2h(bwts_ctx *ctx, Stager &sg, u8 *h_dst, const u8 *d_src, u64 n, bwts_sink_fn sink, void *user)
 {
-    static const int mode = copy_mode("BWTS_D2H");
+    const int mode = copy_mode(ctx, "BWTS_D2H");
     // default: the copy kernel for a single call (54 GB/s against the DMA engine's 29), the DMA engine inside a batch: there the
     // copy runs beside the next item's transform, whose kernels a copy kernel slows down by half (8 x 1 GiB: 18.0 GB/s with the
     // kernel, 24.4 GB/s with the engine -- the transform is the pipeline's slowest stage either way)
@@ -444,7 +479,7 @@ static int staged_d2h(bwts_ctx *ctx, Stager &sg, u8 *h_dst, const u8 *d_src, u64
     }
     // a chunk's first part is moved by the copy kernel, the rest by the DMA engine on the second queue: the two paths
     // add up on the link (BWTS_D2H_SPLIT = percent moved by the kernel)
-    static const int kernel_pct = [] { const char *e = getenv("BWTS_D2H_SPLIT"); int v = e ? atoi(e) : 100; return v < 0 ? 0 : v > 100 ? 100 : v; }();
+    const int kernel_pct = [ctx] { const char *e = bwts_knob(ctx, "BWTS_D2H_SPLIT"); int v = e ? atoi(e) : 100; return v < 0 ? 0 : v > 100 ? 100 : v; }();
     const u64 chunks = (n + STAGE_CHUNK - 1) / STAGE_CHUNK;
     auto issue = [&](u64 c) -> int {
         const u64 off = c * STAGE_CHUNK;
@@ -614,7 +649,7 @@ static int run_batch(bwts_ctx *ctx, device_impl_fn fn, int count, const uint8_t 
     }
     feeder.join();
     drainer.join();
-    if (const char *e = getenv("BWTS_BATCH_TRACE"))
+    if (const char *e = bwts_knob(ctx, "BWTS_BATCH_TRACE"))
         if (e[0] == '1') fprintf(stderr, "[batch] %d items, wall %.1f ms; busy: copy in %.1f, transform %.1f, copy out %.1f ms\n", count, wall_ms() - t_begin, busy[0], busy[1], busy[2]);
     ctx->tm.h2d_ms = 0;
     ctx->tm.d2h_ms = wall_ms() - t_begin;        // (batch: wall time of the whole pipeline; total_ms is the last item's transform)

@@ -527,7 +527,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
 {
     *handled = false;
     if (a0 > 0xffffffffull || a0 < CH_MIN_LIST) return BWTS_OK;
-    static const bool round_trace = [] { const char *e = getenv("BWTS_ROUND_TRACE"); return e && atoi(e) == 1; }();
+    const bool round_trace = [ctx] { const char *e = bwts_knob(ctx, "BWTS_ROUND_TRACE"); return e && atoi(e) == 1; }();
 #define CH_TRY(call) do { const int rc__ = (call); if (rc__ != BWTS_OK) { if (round_trace) fprintf(stderr, "[chunks] line %d: rc %d\n", __LINE__, rc__); return rc__; } } while (0)
 #define CH_HIP(call) do { const hipError_t e__ = (call); if (e__ != hipSuccess) { ctx->last_hip = (int)e__; if (round_trace) fprintf(stderr, "[chunks] line %d: hip error %d\n", __LINE__, (int)e__); return BWTS_E_HIP; } } while (0)
 #define CH_FAIL(why) do { if (round_trace) fprintf(stderr, "[chunks] invariant: %s (round %u)\n", why, rounds); return BWTS_E_INTERNAL; } while (0)
@@ -586,7 +586,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
 
     // ---- big list buffers (the order sort's block, free again) ----
     const size_t m4 = align_up((size_t)m_big * 4, 256), m8 = align_up((size_t)m_big * 8, 256), m1 = align_up((size_t)m_big, 256);
-    static const bool step4_ok = [] { const char *e = getenv("BWTS_DENSE_STEP"); return !(e && atoi(e) == 2); }();
+    const bool step4_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_DENSE_STEP"); return !(e && atoi(e) == 2); }();
     const int nk = step4_ok ? 3 : 1;
     u32 *bl_idx[2] = {nullptr, nullptr}, *bl_head[2] = {nullptr, nullptr}, *t_idx = nullptr, *t_head = nullptr, *bv[2] = {nullptr, nullptr}, *sv1 = nullptr;
     u64 *bk[2] = {nullptr, nullptr}, *k23 = nullptr, *sk1 = nullptr;

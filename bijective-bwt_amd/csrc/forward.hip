@@ -222,7 +222,7 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
     al->sigma = sigma;
     al->bits = bits;
     al->msym = pick_key_symbols(ctx->h_small + SM_HIST, n, bits, 64 / bits);
-    const char *env = getenv("BWTS_KEY_SYMBOLS");              // tuning / test knob: force the symbol count (0 = maximum)
+    const char *env = bwts_knob(ctx, "BWTS_KEY_SYMBOLS");              // tuning / test knob: force the symbol count (0 = maximum)
     if (env) { int v = atoi(env); if (v >= 1 && v <= 64 / bits) al->msym = v; else if (v == 0) al->msym = 64 / bits; }
     al->key_bits = al->bits * al->msym;
     al->varlen = false;
@@ -230,7 +230,7 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
     al->patch_span = al->msym - 1;
     // variable-length codes when they save whole radix passes (skewed alphabets: text); the suffix sort of the general
     // Lyndon path keeps fixed-width codes with the pad symbol
-    const char *vl = getenv("BWTS_VARLEN");                    // 0 = never, 1 = always (tests), unset = when it pays
+    const char *vl = bwts_knob(ctx, "BWTS_VARLEN");                    // 0 = never, 1 = always (tests), unset = when it pays
     if (!reserve_pad && sigma > 1 && !(vl && vl[0] == '0') && !(env && !vl)) {
         u32 vcode[256]; u8 vlen[256];
         double avg = 0, ent = 0;
@@ -311,7 +311,7 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
                     }
                 }
             }
-            const char *kbe = getenv("BWTS_KEY_BITS");
+            const char *kbe = bwts_knob(ctx, "BWTS_KEY_BITS");
             if (kbe) { int v = atoi(kbe); if (v >= 8 && v <= 64) kb = v; }
             const int passes_fixed = (al->key_bits + 7) / 8, passes_var = (kb + 7) / 8;
             // equal pass counts: the variable-length key still holds more symbols when its words are shorter on average
@@ -1967,7 +1967,7 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     ActiveList master{nullptr, nullptr, nullptr};
     u64 act_start[DG_MAX_ACT + 1];
     for (int r = 0; r <= DG_MAX_ACT; r++) act_start[r] = 0;
-    static const bool reorder_ok = [] { const char *e = getenv("BWTS_DENSE_ORDER"); return !(e && atoi(e) == 0); }();
+    const bool reorder_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_DENSE_ORDER"); return !(e && atoi(e) == 0); }();
     const int kb0 = bitlen_u64(2 * n - 1), kb = kb0 > 32 ? kb0 : (kb0 + 7) / 8 * 8;      // (a whole number of digits: the sort then orders by the position field alone)
     if (reorder_ok && a >= (1ull << 16)) {
         // groups in the order of their smallest position (see dg_minpos_kernel); the sorted list lands in sets[0]
@@ -2000,7 +2000,7 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             // +7 %): groups' compositions change every few positions when three or more copies overlap, so runs are short, most
             // groups are activated within four rounds and then wait in the always-active rest like before -- while the flags,
             // ordinals and the partition cost 35 ms.  It pays on inputs that are two copies of one text.
-            static const bool runs_ok = [] { const char *e = getenv("BWTS_DENSE_RUNS"); return e && atoi(e) == 1; }();
+            const bool runs_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_DENSE_RUNS"); return e && atoi(e) == 1; }();
             if (runs_ok) {
                 // activation rounds (see dg_runflags_kernel): flags -> group / run ordinals -> distance to the run's end -> stable
                 // partition of the list by activation round.  Scratch: the rounds' working buffers, not in use yet.
@@ -2038,7 +2038,7 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u64 rest_from = a0;                       // master elements from here on were never activated (only when the loop ends on "no split")
     // the step is quadrupled per round (three successor ranks per element) unless BWTS_DENSE_STEP=2 asks for plain doubling;
     // the activation rounds above are laid out for doubling
-    static const bool step4_ok = [] { const char *e = getenv("BWTS_DENSE_STEP"); return !(e && atoi(e) == 2); }();
+    const bool step4_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_DENSE_STEP"); return !(e && atoi(e) == 2); }();
     const int nk = step4_ok && !by_rounds ? 3 : 1;
     for (u64 h = (u64)al.hstep;; h <<= (nk == 3 ? 2 : 1), act_round++) {
         rounds++;
@@ -2075,7 +2075,7 @@ static int dense_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         u64 m_big = 0;
         for (int c = 0; c < DG_CNT_SPREAD; c++) m_big += ctx->h_small[SM_DGCNT + DG_CNT_BIG + c];
         if (m_big > a) return BWTS_E_INTERNAL;
-        static const bool round_trace = [] { const char *e = getenv("BWTS_ROUND_TRACE"); return e && atoi(e) == 1; }();
+        const bool round_trace = [ctx] { const char *e = bwts_knob(ctx, "BWTS_ROUND_TRACE"); return e && atoi(e) == 1; }();
         if (round_trace) fprintf(stderr, "[rounds] round %u h %llu: list %llu, in larger groups %llu\n", rounds, (unsigned long long)h, (unsigned long long)a, (unsigned long long)m_big);
         if (m_big) {
             // larger groups: compact (with the successor ranks), radix sort by (group ordinal, successor rank), regroup, put back
@@ -2201,7 +2201,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     plan.vals[0] = sp.vals[0]; plan.vals[1] = sp.vals[1];
     plan.tile_hist = sp.tile_hist; plan.scan_temp = sp.scan_temp;
     plan.sym_src = sp.carry_src; plan.sym_buf[0] = sp.carry_buf[0]; plan.sym_buf[1] = sp.carry_buf[1]; plan.sym_final = sp.carry_out;
-    plan.vals_identity = radix_supports_sym();     // keybuild0 writes no value array
+    plan.vals_identity = radix_supports_sym(ctx);     // keybuild0 writes no value array
     plan.keys_split = CYCLIC && sp.split_keys && plan.sym_final && plan.vals_identity;
     if (CYCLIC && sp.split_keys && !plan.keys_split) return BWTS_E_INTERNAL;      // keybuild split the keys for a sort that cannot take them
     if (!plan.vals_identity) {                     // tuning configs without the identity variant: materialise it
@@ -2223,7 +2223,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     const u64 *flag_heads_any = nullptr, *flag_pre_any = nullptr, *flag_keep = nullptr;   // the flag words wherever they live
     u64 flag_words = 0;
     bool rank_early = false;                                  // the dense rank array was built before the tied list
-    static const bool scan_by_keys = [] { const char *e = getenv("BWTS_GROUPSCAN"); return e && !strcmp(e, "keys"); }();
+    const bool scan_by_keys = [ctx] { const char *e = bwts_knob(ctx, "BWTS_GROUPSCAN"); return e && !strcmp(e, "keys"); }();
     if (scan_by_keys) {             // the element-wise scan the later rounds use (kept selectable for tests)
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
         GroupIn in{K0, nullptr, n, -1};
@@ -2262,8 +2262,8 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         // Many ties: the dense rank array.  It is built BEFORE the tied list, while the list's future home (the other key
         // buffer) is still free: the build sorts one u64 per slot between that buffer and the sorted keys' (not needed any
         // more without the sparse rank map).
-        static const bool plain_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
-        static const bool part_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "partition"); }();
+        const bool plain_build = [ctx] { const char *e = bwts_knob(ctx, "BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
+        const bool part_build = [ctx] { const char *e = bwts_knob(ctx, "BWTS_RANKBUILD"); return e && !strcmp(e, "partition"); }();
         if (a > n / 32 && flag_heads && n >= (1ull << 22) && !plain_build && !part_build) {
             BWTS_TRY(ensure_rank(ctx, sp, n));
             SpanGuard g(ctx, BWTS_K_RERANK, n, 28 * n);
@@ -2300,7 +2300,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         if (a > 0xffffffffull) return BWTS_E_NOMEM;
         // few tied elements: sparse rank map; many (real text ties most m-grams): the dense rank array
         const bool sparse = a <= n / 32;
-        static const bool legacy_dense = [] { const char *e = getenv("BWTS_DENSE"); return e && !strcmp(e, "legacy"); }();
+        const bool legacy_dense = [ctx] { const char *e = bwts_knob(ctx, "BWTS_DENSE"); return e && !strcmp(e, "legacy"); }();
         // aux: two key buffers, one value scratch, two list sets (the group-local dense rounds lay out their own, smaller block)
         char *base = nullptr;
         const size_t e4 = align_up((size_t)a * 4, 256), e8 = align_up((size_t)a * 8, 256);
@@ -2331,7 +2331,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             tpos = (u32 *)(base + 2 * e8 + 7 * e4);          // the last two arrays of the aux block
             trank = (u32 *)(base + 2 * e8 + 8 * e4);
             // directory over the sorted keys' top bits for the rank searches of keybuild_sparse_kernel
-            static const bool no_dir = [] { const char *e = getenv("BWTS_K0DIR"); return e && atoi(e) == 0; }();
+            const bool no_dir = [ctx] { const char *e = bwts_knob(ctx, "BWTS_K0DIR"); return e && atoi(e) == 0; }();
             const int kb = al.key_bits;
             dlog = kb < K0_DIR_LOG2_MAX ? kb : K0_DIR_LOG2_MAX;
             if (dlog > bitlen_u64(n)) dlog = bitlen_u64(n);
@@ -2358,7 +2358,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             }
             HIPC(hipGetLastError());
         } else {
-            static const bool plain_build = [] { const char *e = getenv("BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
+            const bool plain_build = [ctx] { const char *e = bwts_knob(ctx, "BWTS_RANKBUILD"); return e && !strcmp(e, "plain"); }();
             BWTS_TRY(ensure_rank(ctx, sp, n));
             if (rank_early) {
                 // built before the tied list (see above)
@@ -2384,7 +2384,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
                 // gather form of the emission)
                 const bool need_sa = !CYCLIC || !sp.carry_out;
                 // chunks (chunk_rounds.h) unless BWTS_DENSE=tiles asks for the second form, the list is short or memory is
-                static const bool tiles_only = [] { const char *e = getenv("BWTS_DENSE"); return e && !strcmp(e, "tiles"); }();
+                const bool tiles_only = [ctx] { const char *e = bwts_knob(ctx, "BWTS_DENSE"); return e && !strcmp(e, "tiles"); }();
                 bool handled = false;
                 if (!tiles_only) BWTS_TRY((chunk_rounds<CYCLIC>(ctx, d_T, n, al, d_fstart, k, sp, cur, a, SA, need_sa, &rounds, &handled)));
                 if (!handled) BWTS_TRY((dense_rounds<CYCLIC>(ctx, d_T, n, al, d_fstart, k, sp, cur, a, SA, need_sa, &rounds)));
@@ -2412,7 +2412,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             }
             const u64 *AK;
             const u32 *AV;
-            static const bool seg_ok = [] { const char *e = getenv("BWTS_SEGSORT"); return !(e && atoi(e) == 0); }();
+            const bool seg_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_SEGSORT"); return !(e && atoi(e) == 0); }();
             // (large groups dominating one round dominate the next one too: then the classification is skipped every other round)
             const bool seg_probe = !seg_skip_next;
             seg_skip_next = false;
@@ -2795,9 +2795,9 @@ static int lyndon_fast(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al, 
     return BWTS_OK;
 }
 
-static int lyndon_mode(void)
+static int lyndon_mode(const bwts_ctx *ctx)
 {
-    const char *env = getenv("BWTS_LYNDON");     // auto (default) | fast | general
+    const char *env = bwts_knob(ctx, "BWTS_LYNDON");     // auto (default) | fast | general
     if (env && !strcmp(env, "general")) return 2;
     if (env && !strcmp(env, "fast")) return 1;
     return 0;
@@ -2818,7 +2818,7 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
     if (!fast_starts) return BWTS_E_NOMEM;
 
     BWTS_TRY(read_histogram(ctx, d_T, n));
-    const int mode = lyndon_mode();
+    const int mode = lyndon_mode(ctx);
     bool done = false;
     *lyndon_rounds = 0;
     if (mode != 2) {
@@ -2826,7 +2826,7 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
         if (!tile_min) return BWTS_E_NOMEM;
         SampleScratch ss{d_T, {sp.keys[0], sp.keys[1]}, {sp.vals[0], sp.vals[1]}, sp.tile_hist, sp.scan_temp};
         BWTS_TRY(set_alphabet(ctx, false, n, al, &ss));
-        sp.split_keys = sp.want_split && radix_packed_applicable(n, al->key_bits);
+        sp.split_keys = sp.want_split && radix_packed_applicable(ctx, n, al->key_bits);
         BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, tile_min, sp.split_keys));
         BWTS_TRY(lyndon_fast(ctx, d_T, n, *al, sp, tile_min, cand, cvals, fast_starts, k_out, &done));
         if (done) *d_fstart = fast_starts;
@@ -2836,7 +2836,7 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
         BWTS_TRY(lyndon_general(ctx, d_T, n, sp, d_fstart, k_out, lyndon_rounds));
         SampleScratch ss{d_T, {sp.keys[0], sp.keys[1]}, {sp.vals[0], sp.vals[1]}, sp.tile_hist, sp.scan_temp};
         BWTS_TRY(set_alphabet(ctx, false, n, al, &ss));
-        sp.split_keys = sp.want_split && radix_packed_applicable(n, al->key_bits);
+        sp.split_keys = sp.want_split && radix_packed_applicable(ctx, n, al->key_bits);
         BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, nullptr, sp.split_keys));
     }
     const KeyStore ks = key_store_of(sp.keys[0], n, sp.split_keys, al->key_bits);
@@ -2949,7 +2949,7 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
     // beyond 32-bit indices: the blocked path with 64-bit positions and ranks (wide_path.h).  BWTS_FORCE_WIDE=1 sends every
     // input there, falling back when the wide form cannot take it; =2 does not fall back (tests)
-    static const int force_wide = [] { const char *e = getenv("BWTS_FORCE_WIDE"); return e ? atoi(e) : 0; }();
+    const int force_wide = [ctx] { const char *e = bwts_knob(ctx, "BWTS_FORCE_WIDE"); return e ? atoi(e) : 0; }();
     if (n > 0x100000000ull || force_wide) {
         const int rc = forward_wide_impl(ctx, d_in, n, d_out);
         if (n > 0x100000000ull || force_wide == 2 || rc != BWTS_E_RANGE) return rc;
@@ -2963,8 +2963,8 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     u32 *d_fstart = nullptr;
     u64 k = 0;
     u32 lrounds = 0;
-    const char *emit_env = getenv("BWTS_EMIT");      // carry (default) | gather
-    const bool carry = radix_supports_sym() && !(emit_env && !strcmp(emit_env, "gather"));
+    const char *emit_env = bwts_knob(ctx, "BWTS_EMIT");      // carry (default) | gather
+    const bool carry = radix_supports_sym(ctx) && !(emit_env && !strcmp(emit_env, "gather"));
     sp.want_split = carry;                           // the byte stream rides round 0 => the packed passes may take split keys
     BWTS_TRY(factors_and_keys(ctx, d_in, n, sp, &al, &d_fstart, &k, &lrounds));
     ctx->tm.factors = k;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <string>
 #include <vector>
 #include <condition_variable>
 #include <mutex>
@@ -99,6 +100,11 @@ struct bwts_ctx {
     // kernels that were granted more than 64 KB of dynamic LDS on this context's device (the attribute is per device)
     std::vector<const void *> lds_granted;
 
+    // environment knobs, read ONCE when the context is made (bwts_knob()): diagnostics and staging tuning always, the switches that
+    // select alternate code paths -- what the test suite drives -- only when BWTS_TEST_KNOBS=1 is set
+    std::vector<std::pair<std::string, std::string>> knobs;
+    int rx_config;         // radix tile shape (BWTS_RX_CONFIG, a tuning knob; 0 = the product shape)
+
     bwts_timings tm;
     double host_ms[BWTS_H_COUNT];   // cumulative host-side costs (BWTS_H_*)
     bool launched;                  // a kernel of this context has run (the code object is loaded)
@@ -117,6 +123,8 @@ void bwts_trace_error(const char *file, int line, int rc);
         int rc__ = (call);               \
         if (rc__ != BWTS_OK) { bwts_trace_error(__FILE__, __LINE__, rc__); return rc__; } \
     } while (0)
+
+const char *bwts_knob(const bwts_ctx *ctx, const char *name);    // value of an environment knob as the context saw it, or null
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 double wall_ms(void);
@@ -169,9 +177,9 @@ struct SortPlan {
     // bits, else u8 (the carried byte).  sym_src is not read; needs sym_final and vals_identity.
     bool keys_split = false;
 };
-bool radix_packed_applicable(u64 m, int key_bits);   // will radix_sort_pairs run its packed-stream passes for such a sort?
-bool radix_supports_sym(void);       // the byte stream is compiled for the default tile shape only
-u64    radix_tiles(u64 m);
+bool radix_packed_applicable(const bwts_ctx *ctx, u64 m, int key_bits);   // will radix_sort_pairs run its packed-stream passes for such a sort?
+bool radix_supports_sym(const bwts_ctx *ctx);       // the byte stream is compiled for the default tile shape only
+u64    radix_tiles(const bwts_ctx *ctx, u64 m);
 size_t radix_tile_hist_bytes(u64 m);
 // Sorts on key bits [0, key_bits); returns in *result_buf which of keys[]/vals[] holds the output.
 int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, int *result_buf);

@@ -861,13 +861,13 @@ __global__ __launch_bounds__(256) void tiny_place_kernel(const uint2 *__restrict
 // ------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------
-static int splitter_log2(u64 n)
+static int splitter_log2(const bwts_ctx *ctx, u64 n)
 {
     int bl = 0; for (u64 x = n; x; x >>= 1) bl++;
     int g = bl - 24;
     if (g < 4) g = 4;
     if (g > 8) g = 8;
-    const char *env = getenv("BWTS_SPLIT_LOG2");
+    const char *env = bwts_knob(ctx, "BWTS_SPLIT_LOG2");
     if (env) { int v = atoi(env); if (v >= 0 && v <= 20) g = v; }
     return g;
 }
@@ -934,7 +934,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     const u64 node_cap = g == 0 ? s : s + s / 8 + 1024;
     const u64 l2cap = node_cap / L2_H + 2 + node_cap;
     u64 walker_cap = 524288;
-    if (const char *e = getenv("BWTS_WALKERS")) { const long v = atol(e); if (v >= 256 && v <= (1 << 22)) walker_cap = (u64)v; }
+    if (const char *e = bwts_knob(ctx, "BWTS_WALKERS")) { const long v = atol(e); if (v >= 256 && v <= (1 << 22)) walker_cap = (u64)v; }
     const u64 walkers = s < walker_cap ? s : walker_cap;
     const unsigned wblocks = (unsigned)((walkers + 255) / 256);
     const u64 log_chunks = n / (IDX_CHUNK - 64) + (u64)wblocks * 4 + 2;     // a closed chunk wastes < 64 entries; every wave may leave one open
@@ -1002,7 +1002,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     if (moments) HIPC(hipMemsetAsync(mom, 0, 3 * mom_classes * sizeof(u64), ctx->stream));
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 6 * n);
-        static const bool syms16 = [] { const char *e = getenv("BWTS_WALK_SYMS"); return e && atoi(e) == 16; }();      // 16-byte symbol stores (A/B against the 64-byte ones)
+        const bool syms16 = [ctx] { const char *e = bwts_knob(ctx, "BWTS_WALK_SYMS"); return e && atoi(e) == 16; }();      // 16-byte symbol stores (A/B against the 64-byte ones)
         if (moments) {
             BWTS_TRY(ensure_dyn_lds(ctx, (const void *)walk_record_kernel<MARK_MOMENTS>, (size_t)MOM_MAX_BUCKETS * 20));
             walk_record_kernel<MARK_MOMENTS><<<dim3(wblocks), dim3(256), (size_t)mom_classes * 20, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
@@ -1094,7 +1094,7 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     BWTS_TRY(read_small(ctx, SMI_COUNTERS, 16));
     const u64 nu = ctx->h_small[SMI_COUNTERS + 1];
     const u64 nu2 = ctx->h_small[SMI_COUNTERS + 6];
-    static const bool inv_trace = [] { const char *e = getenv("BWTS_INV_TRACE"); return e && atoi(e) == 1; }();
+    const bool inv_trace = [ctx] { const char *e = bwts_knob(ctx, "BWTS_INV_TRACE"); return e && atoi(e) == 1; }();
     if (inv_trace && moments)
         fprintf(stderr, "[inverse] moments: shift %d, unreached found %llu, ranges searched %llu, fallback flag %llu\n", mom_shift,
                 (unsigned long long)ctx->h_small[SMI_COUNTERS + 1], (unsigned long long)ctx->h_small[SMI_COUNTERS + 10], (unsigned long long)ctx->h_small[SMI_COUNTERS + 11]);
@@ -1233,25 +1233,25 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
 int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
     // beyond 32-bit indices: the 64-bit form (wide_inverse.h); BWTS_FORCE_WIDE sends every input there (tests)
-    static const int force_wide = [] { const char *e = getenv("BWTS_FORCE_WIDE"); return e ? atoi(e) : 0; }();
+    const int force_wide = [ctx] { const char *e = bwts_knob(ctx, "BWTS_FORCE_WIDE"); return e ? atoi(e) : 0; }();
     if (n > 0x100000000ull || force_wide) return inverse_wide_impl(ctx, d_in, n, d_out);
     bool retry = false, ambiguous = false;
     // how the unreached elements are found: per-range moments (default; falls back to the index log when too many are missing),
     // the index log, or the two mark forms (BWTS_INV_MARK=log|sentinel|bytemap, BWTS_BYTEMARK=1: tests, and the fallback chain below)
     int mark = MARK_MOMENTS;
-    const char *me = getenv("BWTS_INV_MARK");
+    const char *me = bwts_knob(ctx, "BWTS_INV_MARK");
     if (me && !strcmp(me, "log")) mark = MARK_LOG;
     if (me && !strcmp(me, "sentinel")) mark = MARK_SENTINEL;
-    if ((me && !strcmp(me, "bytemap")) || getenv("BWTS_BYTEMARK")) mark = MARK_BYTEMAP;
+    if ((me && !strcmp(me, "bytemap")) || bwts_knob(ctx, "BWTS_BYTEMARK")) mark = MARK_BYTEMAP;
     bool need_log = false;
-    BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous, &need_log));
+    BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(ctx, n), mark, &retry, &ambiguous, &need_log));
     if (need_log) {             // many unreached elements (low-entropy input): the walk again, this time logging every index it visits
         mark = MARK_LOG;
-        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous));
+        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(ctx, n), mark, &retry, &ambiguous));
     }
     if (ambiguous) {            // sentinel marks only, n = 2^32: 0xffffffff was a real entry of a cycle without a splitter
         mark = MARK_BYTEMAP;
-        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(n), mark, &retry, &ambiguous));
+        BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(ctx, n), mark, &retry, &ambiguous));
     }
     if (retry) {
         if (mark == MARK_LOG || mark == MARK_MOMENTS) mark = MARK_SENTINEL;        // adversarial LF: keep the retry on the simplest marks

@@ -39,19 +39,11 @@ static const RxConfig kRxConfigs[] = {{512, 16}, {512, 12}, {256, 16}, {1024, 8}
 #define RX_NCONFIGS ((int)(sizeof(kRxConfigs) / sizeof(kRxConfigs[0])))
 #define RX_DEFAULT_CONFIG 0
 
-static int rx_config_index(void)
-{
-    static int idx = -1;
-    if (idx < 0) {
-        idx = RX_DEFAULT_CONFIG;
-        const char *env = getenv("BWTS_RX_CONFIG");
-        if (env) { int v = atoi(env); if (v >= 0 && v < RX_NCONFIGS) idx = v; }
-    }
-    return idx;
-}
-static u64 rx_tile(void) { const RxConfig &c = kRxConfigs[rx_config_index()]; return (u64)c.threads * c.items; }
+static int rx_config_index(const bwts_ctx *ctx) { return ctx->rx_config; }      // parsed from BWTS_RX_CONFIG when the context was made (api.hip)
+static u64 rx_tile(const bwts_ctx *ctx) { const RxConfig &c = kRxConfigs[rx_config_index(ctx)]; return (u64)c.threads * c.items; }
 
-u64 radix_tiles(u64 m) { return (m + rx_tile() - 1) / rx_tile(); }
+int radix_config_count(void) { return RX_NCONFIGS; }
+u64 radix_tiles(const bwts_ctx *ctx, u64 m) { return (m + rx_tile(ctx) - 1) / rx_tile(ctx); }
 
 static inline u64 radix_chunks(u64 tiles) { return (tiles + RX_CHUNK - 1) / RX_CHUNK; }
 
@@ -819,7 +811,7 @@ int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp)
 {
     const u64 chunks = radix_chunks(tiles);
     u32 *chunk_sum = (u32 *)((char *)tile_hist + align_up((size_t)tiles * 256 * sizeof(u32), 256));
-    static const bool fused_ok = [] { const char *e = getenv("BWTS_RX_FUSED_SCAN"); return !(e && atoi(e) == 0); }();
+    const bool fused_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_RX_FUSED_SCAN"); return !(e && atoi(e) == 0); }();
     if (fused_ok && chunks <= RX_FUSED_CHUNKS) {
         radix_column_scan_fused_kernel<<<dim3((unsigned)chunks), dim3(256), 0, ctx->stream>>>(tile_hist, tiles, (u32)chunks, chunk_sum,
                                                                                              (unsigned int *)(ctx->d_small + SM_RX_SYNC));
@@ -860,13 +852,13 @@ int radix_sort_keys(bwts_ctx *ctx, u64 *keys[2], u32 *tile_hist, void *scan_temp
     return BWTS_OK;
 }
 
-bool radix_supports_sym(void) { return rx_config_index() == 0; }
+bool radix_supports_sym(const bwts_ctx *ctx) { return rx_config_index(ctx) == 0; }
 
-bool radix_packed_applicable(u64 m, int key_bits)
+bool radix_packed_applicable(const bwts_ctx *ctx, u64 m, int key_bits)
 {
-    static const bool packed_ok = [] { const char *e = getenv("BWTS_RX_PACK"); return !(e && atoi(e) == 0); }();
+    const bool packed_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_RX_PACK"); return !(e && atoi(e) == 0); }();
     const int passes = ((key_bits < 1 ? 1 : key_bits) + 7) / 8;
-    return packed_ok && rx_config_index() == 0 && passes >= 3 && passes <= 5 && m >= 65536;
+    return packed_ok && rx_config_index(ctx) == 0 && passes >= 3 && passes <= 5 && m >= 65536;
 }
 
 int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, int *result_buf)
@@ -876,11 +868,11 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
     if (key_bits < 1) key_bits = 1;
     if (key_bits > 64) key_bits = 64;
     const int passes = (key_bits + 7) / 8;
-    const u64 tiles = radix_tiles(m);
-    const int cfg = rx_config_index();
+    const u64 tiles = radix_tiles(ctx, m);
+    const int cfg = rx_config_index(ctx);
     u32 *tile_hist = plan.tile_hist;
 
-    static const bool small_ok = [] { const char *e = getenv("BWTS_RX_SMALL"); return !(e && atoi(e) == 0); }();
+    const bool small_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_RX_SMALL"); return !(e && atoi(e) == 0); }();
     if (small_ok && m <= RS_MAX && !plan.sym_src && !plan.vals_identity && !plan.keys_split) {
         SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, 24 * m);
         radix_sort_small_kernel<<<dim3(1), dim3(RS_THREADS), 0, ctx->stream>>>(plan.keys[0], plan.vals[0], plan.keys[1], plan.vals[1], (u32)m, passes);
@@ -889,7 +881,7 @@ int radix_sort_pairs(bwts_ctx *ctx, const SortPlan &plan, u64 m, int key_bits, i
         return BWTS_OK;
     }
     if (plan.keys_split) {      // round 0 of the forward transform: keybuild left the keys split for the packed passes
-        if (!plan.sym_final || !plan.vals_identity || !radix_packed_applicable(m, key_bits)) return BWTS_E_INTERNAL;
+        if (!plan.sym_final || !plan.vals_identity || !radix_packed_applicable(ctx, m, key_bits)) return BWTS_E_INTERNAL;
         if (passes == 5) return radix_sort_packed<true>(ctx, plan, m, passes, result_buf);
         return radix_sort_packed<false>(ctx, plan, m, passes, result_buf);
     }

@@ -476,8 +476,8 @@ static int inverse_wide_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out,
 static int inverse_wide_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
     // unreached elements from per-range moments; the byte map when too many are missing (or BWTS_INV_MARK=bytemap / BWTS_BYTEMARK=1)
-    const char *me = getenv("BWTS_INV_MARK");
-    bool moments = !((me && !strcmp(me, "bytemap")) || getenv("BWTS_BYTEMARK"));
+    const char *me = bwts_knob(ctx, "BWTS_INV_MARK");
+    bool moments = !((me && !strcmp(me, "bytemap")) || bwts_knob(ctx, "BWTS_BYTEMARK"));
     bool need_marks = false;
     if (moments) {
         BWTS_TRY(inverse_wide_attempt(ctx, d_in, n, d_out, true, &need_marks));
@@ -496,7 +496,7 @@ static int inverse_wide_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out,
     const u64 node_cap = s + s / 8 + 1024;
     if (node_cap > 0xfffffff0ull) return BWTS_E_RANGE;
     int seg_log2 = 31;
-    if (const char *e = getenv("BWTS_WIDE_SEG_LOG2")) { const int v = atoi(e); if (v >= 12 && v <= 31) seg_log2 = v; }
+    if (const char *e = bwts_knob(ctx, "BWTS_WIDE_SEG_LOG2")) { const int v = atoi(e); if (v >= 12 && v <= 31) seg_log2 = v; }
     const u64 segn = 1ull << seg_log2;
     const u64 nseg = (n + segn - 1) / segn;
     const size_t need = align_up(n * 8, 256) + align_up(n, 256) + align_up(node_cap * slot, 256) + align_up(node_cap * sizeof(WiNode), 256) +

@@ -204,21 +204,21 @@ struct WideRestOut {
 };
 
 struct WideKnobs { int seg_log2; u64 bucket_cap; };
-static WideKnobs wide_knobs(void)
+static WideKnobs wide_knobs(const bwts_ctx *ctx)
 {
     WideKnobs kn{30, 1ull << 30};
-    if (const char *e = getenv("BWTS_WIDE_SEG_LOG2")) { const int v = atoi(e); if (v >= 11 && v <= 31) kn.seg_log2 = v; }      // >= log2(KB_TILE)
-    if (const char *e = getenv("BWTS_WIDE_BUCKET")) { const long long v = atoll(e); if (v >= 256 && v <= 0xff000000ll) kn.bucket_cap = (u64)v; }
+    if (const char *e = bwts_knob(ctx, "BWTS_WIDE_SEG_LOG2")) { const int v = atoi(e); if (v >= 11 && v <= 31) kn.seg_log2 = v; }      // >= log2(KB_TILE)
+    if (const char *e = bwts_knob(ctx, "BWTS_WIDE_BUCKET")) { const long long v = atoll(e); if (v >= 256 && v <= 0xff000000ll) kn.bucket_cap = (u64)v; }
     return kn;
 }
 
 static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
 {
     if (n > (1ull << 36)) return BWTS_E_RANGE;
-    WideKnobs kn = wide_knobs();
+    WideKnobs kn = wide_knobs(ctx);
     // larger buckets (fewer collection passes over the text) while rank array + bucket buffers + in/out leave room: 12 GiB of DNA
     // take 2.03 s with buckets of 2^30 elements (before the carried byte), 1.86 s with 2^31, 1.62 s with 3 * 2^30 (203 GiB on the device)
-    if (!getenv("BWTS_WIDE_BUCKET")) {
+    if (!bwts_knob(ctx, "BWTS_WIDE_BUCKET")) {
         if (n <= (13ull << 30)) kn.bucket_cap = 3ull << 30;
         else if (n <= (14ull << 30)) kn.bucket_cap = 1ull << 31;
     }
@@ -346,7 +346,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     }
     ctx->tm.factors = k;
     const PrevSym64 prev{d_T, n, fstart, k};
-    static const bool carry_ok = [] { const char *e = getenv("BWTS_WIDE_CARRY"); return !(e && atoi(e) == 0); }();
+    const bool carry_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_WIDE_CARRY"); return !(e && atoi(e) == 0); }();
     // the output byte travels with the sort (see WideFilterOut): the passes cover whole bytes of the key, so the parked bits must lie above them
     const bool carry = carry_ok && 8 * ((al.key_bits + 7) / 8) <= WIDE_HI_SHIFT;
 

@@ -479,7 +479,7 @@ def test_cli_in_place_and_failure_leaves_nothing(tmp_path):
     a_n.write_bytes(b"a" * 100000)
     dest = tmp_path / "precious.bwts"
     dest.write_bytes(b"keep me")
-    env = dict(os.environ, BWTS_FORCE_WIDE="2")
+    env = dict(os.environ, BWTS_TEST_KNOBS="1", BWTS_FORCE_WIDE="2")
     r = _run_cli([os.path.join(PKG, "mk_bwts"), str(a_n), str(dest)], env=env)
     assert r.returncode == 1 and b"transform failed" in r.stderr and dest.read_bytes() == b"keep me"
     before = set(os.listdir(tmp_path))
@@ -654,7 +654,7 @@ with pkg.Context(0) as ctx:
         assert np.array_equal(ctx.inverse(x), O.inverse(x))
 print("wide ok")
 """ % (ROOT, os.path.join(ROOT, "tests"), WIDE_CASES)
-    env = dict(os.environ, BWTS_TEST_CHILD="1", BWTS_FORCE_WIDE="2", BWTS_WIDE_SEG_LOG2="13")
+    env = dict(os.environ, BWTS_TEST_CHILD="1", BWTS_TEST_KNOBS="1", BWTS_FORCE_WIDE="2", BWTS_WIDE_SEG_LOG2="13")
     proc = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
     out, _ = proc.communicate(timeout=900)
     _wait_gpu_handle_released(proc.pid)
@@ -767,7 +767,7 @@ with pkg.Context(0) as ctx:
     assert ctx.device_equal(a, c, n)                # the main inverse turns it back into the input
 print("wide ok")
 """ % (ROOT,)
-    env = dict(os.environ, BWTS_TEST_CHILD="1", BWTS_FORCE_WIDE="2", BWTS_WIDE_SEG_LOG2="27", BWTS_WIDE_BUCKET=str(1 << 27))
+    env = dict(os.environ, BWTS_TEST_CHILD="1", BWTS_TEST_KNOBS="1", BWTS_FORCE_WIDE="2", BWTS_WIDE_SEG_LOG2="27", BWTS_WIDE_BUCKET=str(1 << 27))
     proc = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
     out, _ = proc.communicate(timeout=900)
     _wait_gpu_handle_released(proc.pid)
@@ -804,7 +804,7 @@ def test_text_1GiB_golden_and_properties(ctx):
 
 
 # ---------------------------------------------------------------------------------------------
-# alternate code paths, selected by environment knobs (read once per process -> one child process per mode)
+# alternate code paths, selected by environment knobs (read once per context, and only under BWTS_TEST_KNOBS=1 -> one child process per mode)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("env", [
     {"BWTS_VARLEN": "1", "BWTS_KEY_BITS": "24"},      # variable-length key codes on every input, narrow keys: many ties, sparse ranks
@@ -836,7 +836,7 @@ def test_alternate_paths(env):
     # makes the child select this very test and start a child of its own.)
     if os.environ.get("BWTS_TEST_CHILD"):
         pytest.skip("already inside a child run")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, BWTS_TEST_CHILD="1", **env), cwd=ROOT)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, BWTS_TEST_CHILD="1", BWTS_TEST_KNOBS="1", **env), cwd=ROOT)
     try:
         out, _ = proc.communicate(timeout=900)
     except subprocess.TimeoutExpired:
@@ -844,6 +844,27 @@ def test_alternate_paths(env):
         out, _ = proc.communicate()
     _wait_gpu_handle_released(proc.pid)
     assert proc.returncode == 0, out.decode()[-3000:]
+
+
+def test_stray_knobs_are_ignored_without_the_gate(pkg):
+    """A process that merely inherits BWTS_* variables runs the product paths: the switches for alternate code paths count only
+    under BWTS_TEST_KNOBS=1, and a context reads its environment once, when it is made."""
+    x = O.generate("zipf", 200000, 77)
+    os.environ["BWTS_FORCE_WIDE"] = "2"
+    os.environ["BWTS_KEY_BITS"] = "8"
+    try:
+        with pkg.Context(0) as c:
+            y = c.forward(x)
+            t = c.timings()
+            assert t.key_bits > 8                              # not the forced width: the knob was not looked at
+            assert np.array_equal(y, O.forward(x))
+        os.environ["BWTS_TEST_KNOBS"] = "1"
+        with pkg.Context(0) as c:
+            y = c.forward(x)
+            assert c.timings().key_bits == 8 and np.array_equal(y, O.forward(x))
+    finally:
+        for k in ("BWTS_FORCE_WIDE", "BWTS_KEY_BITS", "BWTS_TEST_KNOBS"):
+            os.environ.pop(k, None)
 
 
 def test_smoke_entry():

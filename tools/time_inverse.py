@@ -1,5 +1,6 @@
 """Manual check (GPU box): inverse timing per kernel class for several splitter spacings (BWTS_SPLIT_LOG2).
     python tools/time_inverse.py [kind] [log2n] [g ...]"""
+import os as _os; _os.environ.setdefault("BWTS_TEST_KNOBS", "1")      # this tool drives alternate-path knobs
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge

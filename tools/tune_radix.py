@@ -1,4 +1,5 @@
 """Manual tuning helper (GPU box): times the LSD passes for the tile shape selected by BWTS_RX_CONFIG."""
+import os as _os; _os.environ.setdefault("BWTS_TEST_KNOBS", "1")      # this tool drives alternate-path knobs
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
