@@ -1375,8 +1375,9 @@ __global__ __launch_bounds__(256) void seg_writeback_kernel(const u64 *__restric
 // everything), and one kernel does a whole round for every group of at most DG_CAP elements:
 //   gather r = rank[successor] -> order the members by r (LDS, counting) -> subgroups of equal r: new head = head + number
 //   of smaller members -> members that are alone are finished: their rank is final and their output byte is written;
-//   the others stay, with their new head.  rank[] is updated in place: a successor rank read in the same round may already
-//   be refined, which orders at least as finely as the unrefined one and never differently (ranks only ever split).
+//   the others stay, with their new head.  rank[] is only READ during a round -- a member that already shows its new rank next to a
+//   group-mate that still shows the old one would order the wrong way round -- and the new ranks are applied when the round's
+//   gathers are done (dg_compact_kernel here, chunk_apply_moves_kernel in the chunk form).
 // Larger groups (a few per cent of the elements after the first rounds) are flagged, compacted, ordered by the radix
 // sort, regrouped with a scan and put back.  A stable compaction of the surviving elements gives the next round's list.
 #ifndef DG_CAP

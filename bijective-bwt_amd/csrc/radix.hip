@@ -812,7 +812,15 @@ int radix_column_scan(bwts_ctx *ctx, u32 *tile_hist, u64 tiles, void *scan_temp)
     const u64 chunks = radix_chunks(tiles);
     u32 *chunk_sum = (u32 *)((char *)tile_hist + align_up((size_t)tiles * 256 * sizeof(u32), 256));
     const bool fused_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_RX_FUSED_SCAN"); return !(e && atoi(e) == 0); }();
-    if (fused_ok && chunks <= RX_FUSED_CHUNKS) {
+    if (ctx->fused_scan_cap == 0) {
+        // every workgroup of the fused kernel waits for all the others: it may only be used with as many workgroups as the device
+        // is certain to hold at once (a whole MI355X: 256 CUs x 8; a partition of it, or a CU-masked queue, fewer)
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, radix_column_scan_fused_kernel, 256, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        ctx->fused_scan_cap = per_cu > 0 && cus > 0 ? per_cu * cus : -1;
+    }
+    if (fused_ok && chunks <= RX_FUSED_CHUNKS && (long long)chunks <= (long long)ctx->fused_scan_cap) {
         radix_column_scan_fused_kernel<<<dim3((unsigned)chunks), dim3(256), 0, ctx->stream>>>(tile_hist, tiles, (u32)chunks, chunk_sum,
                                                                                              (unsigned int *)(ctx->d_small + SM_RX_SYNC));
         HIPC(hipGetLastError());

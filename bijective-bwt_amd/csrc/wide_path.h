@@ -15,7 +15,7 @@
 //   * the tied list (small unless the input is repetitive) goes through rounds of (group, rank of the h-th cyclic successor)
 //     sorting with 64-bit ranks until no group splits.
 // Memory: rank array 8 n, one segment of keys, one bucket's sort buffers: ~160 GiB at n = 12 GiB, against ~430 GiB for the
-// main path's layout.  The inverse transform has no wide path yet (out of core).
+// main path's layout.  The inverse's 64-bit form is wide_inverse.h (dispatched from inverse_device_impl).
 #define WIDE_PREFIX_BITS 12
 #define WIDE_PREFIXES    (1u << WIDE_PREFIX_BITS)
 #define WIDE_TIED_CAP    (1ull << 28)
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void wide_bucket_finish_kernel(const u64 *__re
                                                                  const u64 *__restrict__ headw, const u64 *__restrict__ keepw, const u64 *__restrict__ pre,
                                                                  u64 *__restrict__ rank64, PrevSym64 prev, u8 *__restrict__ out,
                                                                  const u64 *__restrict__ tied_count, u64 tied_cap, u64 *__restrict__ tpos, u64 *__restrict__ thead,
-                                                                 u64 *__restrict__ overflow)
+                                                                 u64 *__restrict__ overflow, u64 n)
 {
     const int lane = lane_id();
     const u64 tbase = *tied_count;
@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256) void wide_bucket_finish_kernel(const u64 *__re
         const u64 hloc = below ? (w << 6) + (u64)(63 - __clzll((long long)below)) : (pr >> 32);
         const u64 p = (u64)V[i] | ((CARRY ? K[i] >> WIDE_HI_SHIFT : (u64)S[i]) << 32);
         const u64 r = base + hloc;
+        // (a position rebuilt from sorted data: should key build and prefix histogram ever disagree again, this is an error code,
+        // not a write through a stale position -- the GPU fault of round 2's fuzz run)
+        if (p >= n) { *overflow = 2; continue; }
         rank64[p] = r;
         out[base + i] = CARRY ? S[i] : prev(p);
         if ((km >> lane) & 1ull) {
@@ -450,10 +453,10 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
             u64 blocks = (m + 255) / 256; if (blocks > 16384) blocks = 16384;
             if (carry)
                 wide_bucket_finish_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], sp.vals[res], bs_fin, m, base, headw, keepw, prew,
-                                                                                                      rank64, prev, d_out, d_tied, tied_cap, tpos[0], thead[0], d_over);
+                                                                                                      rank64, prev, d_out, d_tied, tied_cap, tpos[0], thead[0], d_over, n);
             else
                 wide_bucket_finish_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], sp.vals[res], bs_fin, m, base, headw, keepw, prew,
-                                                                                                       rank64, prev, d_out, d_tied, tied_cap, tpos[0], thead[0], d_over);
+                                                                                                       rank64, prev, d_out, d_tied, tied_cap, tpos[0], thead[0], d_over, n);
             wide_add_tied_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(keepw, prew, words, d_tied);
             HIPC(hipGetLastError());
         }
@@ -462,6 +465,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     if (base != n) return BWTS_E_INTERNAL;
     BWTS_TRY(read_small(ctx, SM_COUNTERS + 24, 2));
     u64 a = ctx->h_small[SM_COUNTERS + 24];
+    if (ctx->h_small[SM_COUNTERS + 25] == 2) return BWTS_E_INTERNAL;              // a sorted element carried a position outside the text
     if (ctx->h_small[SM_COUNTERS + 25] || a > tied_cap) return BWTS_E_NOMEM;      // more tied elements than the tied list holds
     ctx->tm.active_after_round0 = a;
     ctx->tm.round_active[0] = a;
