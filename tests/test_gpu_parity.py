@@ -798,6 +798,23 @@ def test_text_16MiB_vs_oracle(ctx):
     assert np.array_equal(ctx.inverse(y), x)
 
 
+def test_real_text_vs_oracle(ctx):
+    """Real text with long repeats -- source and documentation files of this image, 53.6 MiB, 205 distinct bytes, 82 % of the positions
+    tied after round 0, groups of thousands of members: the device's bytes against the oracle run here on the same bytes and
+    against its golden hash (tests/golden/realtext.json); skipped where the image's files differ from the golden's."""
+    import realtext
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "realtext.json")))
+    x = np.frombuffer(realtext.corpus(1 << gold["limit_log2"]), dtype=np.uint8)
+    if x.size != gold["n"] or hashlib.sha256(x.tobytes()).hexdigest() != gold["sha256_in"]:
+        pytest.skip("this box's file set is not the golden's")
+    y = ctx.forward(x)
+    t = ctx.timings()
+    assert t.active_after_round0 > x.size // 2 and t.rounds >= 6
+    assert hashlib.sha256(y.tobytes()).hexdigest() == gold["sha256_bwts"]
+    assert np.array_equal(y, O.forward(x))
+    assert np.array_equal(ctx.inverse(y), x)
+
+
 def test_text_1GiB_golden_and_properties(ctx):
     """The bench's text workload at full size, byte-exact against the oracle's golden, then the properties."""
     _properties_at_scale(ctx, "text", 1 << 30, 1, golden=True)

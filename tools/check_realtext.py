@@ -6,20 +6,7 @@ import numpy as np
 import oracle_lib as O
 import __graft_entry__ as ge
 
-def corpus(limit):
-    out, total = [], 0
-    for root in ("/usr/lib/python3/dist-packages", "/usr/lib/python3.10", "/usr/share/doc", "/usr/include"):
-        for d, _, files in sorted(os.walk(root)):
-            for f in sorted(files):
-                if not f.endswith((".py", ".txt", ".h", ".hpp", ".md", ".rst", ".c", ".json", ".html")): continue
-                p = os.path.join(d, f)
-                try:
-                    b = open(p, "rb").read()
-                except OSError:
-                    continue
-                out.append(b); total += len(b)
-                if total >= limit: return b"".join(out)[:limit]
-    return b"".join(out)
+from realtext import corpus          # tests/realtext.py: the same corpus the gpu test uses
 
 limit = (1 << int(sys.argv[1])) if len(sys.argv) > 1 else 1 << 26
 x = np.frombuffer(corpus(limit), dtype=np.uint8)
