@@ -312,7 +312,7 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
                 }
             }
             const char *kbe = bwts_knob(ctx, "BWTS_KEY_BITS");
-            if (kbe) { int v = atoi(kbe); if (v >= 8 && v <= 64) kb = v; }
+            if (kbe) { int v = atoi(kbe); if (v >= 8 && v >= lmax && v <= 64) kb = v; }       // (a key must hold its first symbol whole: the first step is >= 1)
             const int passes_fixed = (al->key_bits + 7) / 8, passes_var = (kb + 7) / 8;
             // equal pass counts: the variable-length key still holds more symbols when its words are shorter on average
             if ((vl && vl[0] == '1') || passes_var < passes_fixed || (passes_var == passes_fixed && avg < (double)bits - 0.25)) {

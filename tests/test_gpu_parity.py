@@ -868,17 +868,18 @@ def test_stray_knobs_are_ignored_without_the_gate(pkg):
     under BWTS_TEST_KNOBS=1, and a context reads its environment once, when it is made."""
     x = O.generate("zipf", 200000, 77)
     os.environ["BWTS_FORCE_WIDE"] = "2"
-    os.environ["BWTS_KEY_BITS"] = "8"
+    os.environ["BWTS_KEY_BITS"] = "16"
     try:
         with pkg.Context(0) as c:
             y = c.forward(x)
             t = c.timings()
-            assert t.key_bits > 8                              # not the forced width: the knob was not looked at
+            assert t.key_bits > 16                             # not the forced width: the knob was not looked at
             assert np.array_equal(y, O.forward(x))
         os.environ["BWTS_TEST_KNOBS"] = "1"
+        del os.environ["BWTS_FORCE_WIDE"]
         with pkg.Context(0) as c:
             y = c.forward(x)
-            assert c.timings().key_bits == 8 and np.array_equal(y, O.forward(x))
+            assert c.timings().key_bits == 16 and np.array_equal(y, O.forward(x))
     finally:
         for k in ("BWTS_FORCE_WIDE", "BWTS_KEY_BITS", "BWTS_TEST_KNOBS"):
             os.environ.pop(k, None)
