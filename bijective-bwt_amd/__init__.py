@@ -62,7 +62,7 @@ class Timings(ctypes.Structure):
                 ("lyndon_rounds", ctypes.c_uint32), ("key_symbols", ctypes.c_uint32), ("key_bits", ctypes.c_uint32),
                 ("active_after_round0", ctypes.c_uint64), ("unvisited", ctypes.c_uint64), ("device_bytes", ctypes.c_uint64),
                 ("round_active", ctypes.c_uint64 * MAX_ROUND_STATS), ("k", KernelStat * K_COUNT),
-                ("host_ms", ctypes.c_double * H_COUNT)]
+                ("host_ms", ctypes.c_double * H_COUNT), ("attempts", ctypes.c_uint32), ("reserved_", ctypes.c_uint32)]
 
     def as_dict(self):
         d = {f: getattr(self, f) for f, _ in self._fields_ if f not in ("k", "round_active", "host_ms")}

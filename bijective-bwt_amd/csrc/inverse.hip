@@ -1244,6 +1244,7 @@ int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
 {
     // beyond 32-bit indices: the 64-bit form (wide_inverse.h); BWTS_FORCE_WIDE sends every input there (tests)
     const int force_wide = [ctx] { const char *e = bwts_knob(ctx, "BWTS_FORCE_WIDE"); return e ? atoi(e) : 0; }();
+    ctx->tm.attempts = 1;
     if (n > 0x100000000ull || force_wide) return inverse_wide_impl(ctx, d_in, n, d_out);
     bool retry = false, ambiguous = false;
     // how the unreached elements are found: per-range moments (default; falls back to the index log when too many are missing),
@@ -1254,19 +1255,25 @@ int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     if (me && !strcmp(me, "sentinel")) mark = MARK_SENTINEL;
     if ((me && !strcmp(me, "bytemap")) || bwts_knob(ctx, "BWTS_BYTEMARK")) mark = MARK_BYTEMAP;
     bool need_log = false;
+    // Worst case: the walk runs up to five times (moments -> index log -> byte map at n = 2^32 -> every element a splitter, with
+    // sentinel and then byte-map marks); natural inputs take one.  bwts_timings.attempts says how many it was.
+    ctx->tm.attempts = 1;
     BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(ctx, n), mark, &retry, &ambiguous, &need_log));
     if (need_log) {             // many unreached elements (low-entropy input): the walk again, this time logging every index it visits
         mark = MARK_LOG;
+        ctx->tm.attempts++;
         BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(ctx, n), mark, &retry, &ambiguous));
     }
     if (ambiguous) {            // sentinel marks only, n = 2^32: 0xffffffff was a real entry of a cycle without a splitter
         mark = MARK_BYTEMAP;
+        ctx->tm.attempts++;
         BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, splitter_log2(ctx, n), mark, &retry, &ambiguous));
     }
     if (retry) {
         if (mark == MARK_LOG || mark == MARK_MOMENTS) mark = MARK_SENTINEL;        // adversarial LF: keep the retry on the simplest marks
+        ctx->tm.attempts++;
         BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, mark, &retry, &ambiguous));
-        if (ambiguous) BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, MARK_BYTEMAP, &retry, &ambiguous));
+        if (ambiguous) { ctx->tm.attempts++; BWTS_TRY(inverse_attempt(ctx, d_in, n, d_out, 0, MARK_BYTEMAP, &retry, &ambiguous)); }
         if (retry || ambiguous) return BWTS_E_INTERNAL;
     }
     return BWTS_OK;

@@ -96,6 +96,8 @@ typedef struct bwts_timings {
     uint64_t round_active[BWTS_MAX_ROUND_STATS]; /* forward: elements still tied when sort round r+1 starts (r = 0: after round 0) */
     bwts_kernel_stat k[BWTS_K_COUNT];
     double   host_ms[BWTS_H_COUNT]; /* cumulative since bwts_ctx_create (BWTS_H_*): start-up and allocation costs           */
+    uint32_t attempts;              /* inverse: times the cycle walk ran (1 on natural inputs, at most 5: see bwts_inverse)  */
+    uint32_t reserved_;
 } bwts_timings;
 
 int  bwts_ctx_create(bwts_ctx **out, int device_id);
@@ -105,6 +107,11 @@ void bwts_ctx_destroy(bwts_ctx *ctx);
  * mmap of a file, unpinned); staged through pinned buffers with hipMemcpyAsync. */
 int bwts_forward(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out);
 int bwts_inverse(bwts_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out);
+/* Cost bounds (n <= 2^32; bwts_timings.device_bytes reports what a context actually holds).  Forward: about 25 n bytes of device
+ * memory for inputs whose positions the first sort separates (plus 4 n for the rank array and 16-33 bytes per position that stays
+ * tied when it does not: text with long repeats; plus 3 n when the first sort runs on keys wider than 40 bits).  Inverse: about
+ * 11 n, plus ~110 bytes per element that lies in a long LF cycle without a splitter (sorted or periodic data); its cycle walk runs
+ * once on natural inputs and at most five times on adversarial ones (bwts_timings.attempts). */
 
 /* Same transforms, the result handed to a callback in consecutive pieces (in order, together n bytes) straight from the
  * pinned staging buffers: a CLI passes an fwrite wrapper and never holds an n-byte output buffer (mk_bwts_sa.c:60,

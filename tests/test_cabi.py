@@ -39,10 +39,10 @@ def test_strerror_and_names(pkg):
 
 
 def test_timings_struct_layout_matches_header(pkg):
-    # bwts_timings: 3 doubles, 2 u64, 4 u32, 3 u64, the per-round counts, K_COUNT * (double + 3 u64), then H_COUNT doubles
+    # bwts_timings: 3 doubles, 2 u64, 4 u32, 3 u64, the per-round counts, K_COUNT * (double + 3 u64), H_COUNT doubles, then 2 u32
     import ctypes
     assert ctypes.sizeof(pkg.KernelStat) == 32
-    assert ctypes.sizeof(pkg.Timings) == 3 * 8 + 2 * 8 + 4 * 4 + 3 * 8 + pkg.MAX_ROUND_STATS * 8 + pkg.K_COUNT * 32 + pkg.H_COUNT * 8
+    assert ctypes.sizeof(pkg.Timings) == 3 * 8 + 2 * 8 + 4 * 4 + 3 * 8 + pkg.MAX_ROUND_STATS * 8 + pkg.K_COUNT * 32 + pkg.H_COUNT * 8 + 8
     L = pkg.lib()
     L.bwts_host_cost_name.restype = ctypes.c_char_p
     assert [L.bwts_host_cost_name(i).decode() for i in range(pkg.H_COUNT)] == pkg.H_NAMES
