@@ -124,7 +124,6 @@ def test_large_reference_unbwts_hashes(ctx, rec):
     assert np.array_equal(ctx.forward(x), y)
 
 
-@pytest.mark.parametrize("kind,n,seed", [("zipf", 4 << 20, 11), ("dna", 3000017, 12), ("uniform256", (2 << 20) + 5, 13)])
 def test_inverse_attempts_reported(ctx):
     """bwts_timings.attempts: the cycle walk runs once on natural inputs; a constant input (every element its own LF cycle, nearly all
     of them unreached by any splitter walk) needs the index log: two attempts."""
@@ -134,6 +133,7 @@ def test_inverse_attempts_reported(ctx):
     assert np.array_equal(ctx.inverse(z), z) and 1 <= ctx.timings().attempts <= 5
 
 
+@pytest.mark.parametrize("kind,n,seed", [("zipf", 4 << 20, 11), ("dna", 3000017, 12), ("uniform256", (2 << 20) + 5, 13)])
 def test_mid_size_vs_oracle(ctx, kind, n, seed):
     x = O.generate(kind, n, seed)
     y = ctx.forward(x)
