@@ -841,9 +841,11 @@ def test_text_1GiB_golden_and_properties(ctx):
     {"BWTS_RX_PACK": "0"},                            # round-0 sort on wide (u64, u32, u8) streams instead of packed ones
     {"BWTS_GROUPSCAN": "keys"},                       # round-0 group scan element-wise over the keys instead of flag words
     {"BWTS_RANKBUILD": "plain"},
-    {"BWTS_DENSE_RUNS": "1"},                         # activation rounds from the run structure of the position-ordered list (opt-in)
+    {"BWTS_DENSE": "tiles", "BWTS_DENSE_RUNS": "1"},  # (tile form) activation rounds from the run structure of the position-ordered list (opt-in)
     {"BWTS_DENSE_STEP": "2"},                         # group-local rounds with plain doubling (one successor rank) instead of the quadrupled step
-    {"BWTS_DENSE_ORDER": "0"},                        # ... and without ordering the list by position
+    {"BWTS_DENSE": "tiles", "BWTS_DENSE_STEP": "2"},
+    {"BWTS_DENSE": "tiles"},                          # the tile form of the group-local rounds (round 2) instead of the chunked one
+    {"BWTS_DENSE": "tiles", "BWTS_DENSE_ORDER": "0"}, # ... and without ordering the list by position
     {"BWTS_DENSE": "legacy"},                         # later rounds with many ties: list in SA order, radix-sorted, instead of the group-local rounds
     {"BWTS_DENSE": "legacy", "BWTS_SEGSORT": "0"},                            # later rounds: radix sort of the whole tied list instead of sorting small groups in place
     {"BWTS_RX_SMALL": "0"},                           # small sorts through the multi-launch passes instead of the one-workgroup kernel
