@@ -294,11 +294,13 @@ static int set_alphabet(bwts_ctx *ctx, bool reserve_pad, u64 n, Alphabet *al, co
                     if (kb_emp > kb) {
                         // Repeats, not entropy, tie these positions, and no key width separates the copies of a long repeat: the
                         // rounds on the tied list will.  Wider keys then only pay where they lengthen the first step (key bits /
-                        // longest code word) -- with short code words the model's width, at least five digits, already gives a step
+                        // longest code word) -- with short code words five digits (the packed passes) already give a step
                         // of four symbols, and three fewer n-sized passes beat the few per cent of extra list elements (text 2^30,
                         // longest code 9 bits: 64 / 48 / 40 / 32 key bits = 169 / 160 / 143 / 159 ms); with long code words (real
                         // text: 205 symbols, 16 bits) every key bit counts (53.6 MiB: 16.1 / 18.5 / 20.6 / 23.3 ms).
-                        const int keep = kb < 40 ? 40 : kb;
+                        // (five packed digits whatever the model asks for at this n: text 2^31 / 2^32 with 48 against 40 bits = 334 / 660
+                        // against 295 / 590 ms)
+                        const int keep = 40;
                         if (keep / lmax >= 4) kb = keep;
                         else {
                             kb = kb_emp;
