@@ -408,17 +408,125 @@ __global__ __launch_bounds__(256) void chunk_rest_kernel(const u32 *__restrict__
     }
 }
 
-// first list slot of the larger groups: the one-off order puts them behind everything else (sort key >= n)
-__global__ void chunk_find_big_kernel(const u64 *__restrict__ keys, u64 a, int sort_bits, u64 first_big_key, unsigned long long *__restrict__ result)
+// ---- the one-off order, by GROUP RECORDS ----------------------------------------------------------------------------------------
+// The list only has to come out with its groups in the order of their smallest positions.  Sorting the elements for that (round 2, and
+// the first form of this file) moves 32 bytes per element and pass; the groups are two or three members each on text, so one record per
+// group -- (size << 32 | smallest position, list index of its first member) -- is sorted instead, the sizes are scanned in sorted order
+// and the members copied to their places (go_expand_kernel).  Members of groups larger than CH_CAP are not ordered at all: they are
+// compacted, in list (= SA) order, behind everything else and become the big list.
+// tile_counts[t] (exclusive-scanned in place before go_write_kernel; entry [tiles] = totals): low word = group records, high = big elements
+__global__ __launch_bounds__(DG_THREADS) void go_count_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, u64 a, u64 *__restrict__ tile_counts)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    const u64 mask = sort_bits >= 64 ? ~0ull : ((1ull << sort_bits) - 1ull);
-    u64 lo = 0, hi = a;
-    while (lo < hi) {
-        const u64 mid = (lo + hi) >> 1;
-        if ((keys[mid] & mask) < first_big_key) lo = mid + 1; else hi = mid;
+    __shared__ u32 hd[DG_SPAN];
+    __shared__ u64 startm[DG_SPAN / 64];
+    __shared__ u64 wsum[DG_THREADS / 64];
+    const int tid = threadIdx.x;
+    const long long e0 = (long long)blockIdx.x * DG_OWN - DG_CAP;
+    DgSlots ds;
+    dg_detect(idx, head, a, e0, hd, startm, ds);
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const u32 sl = (u32)j * DG_THREADS + tid;
+        if (ds.kind[j] == 1 && ds.gs[j] == sl) c += 1ull;
+        if (ds.kind[j] == 2) c += 1ull << 32;
     }
-    *result = lo;
+    c = wave_scan_inclusive(c, OpAdd());
+    if (lane_id() == 63) wsum[wave_id()] = c;
+    __syncthreads();
+    if (tid == 0) { u64 t = 0; for (int w = 0; w < DG_THREADS / 64; w++) t += wsum[w]; tile_counts[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(DG_THREADS) void go_write_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, u64 a, const u64 *__restrict__ tile_off, u64 tiles,
+                                                              u64 *__restrict__ rkeys, u32 *__restrict__ rvals, u32 *__restrict__ st_idx, u32 *__restrict__ st_head,
+                                                              bool pairs /* n <= 2^31: bit 31 of a position is free to tell the two record forms apart */)
+{
+    __shared__ u32 hd[DG_SPAN];
+    __shared__ u32 pos[DG_SPAN];
+    __shared__ u64 startm[DG_SPAN / 64];
+    __shared__ u32 wcnt[2][DG_ITEMS][DG_THREADS / 64];           // per (item row, wave): records, big elements -- rows are consecutive slot ranges
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long e0 = (long long)blockIdx.x * DG_OWN - DG_CAP;
+    DgSlots ds;
+    dg_detect(idx, head, a, e0, hd, startm, ds);
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++)
+        if (ds.kind[j] == 1) pos[j * DG_THREADS + tid] = ds.idx[j];
+    u64 rm[DG_ITEMS], bm[DG_ITEMS];
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        const u32 sl = (u32)j * DG_THREADS + tid;
+        rm[j] = __ballot(ds.kind[j] == 1 && ds.gs[j] == sl);
+        bm[j] = __ballot(ds.kind[j] == 2);
+        if (lane == 0) { wcnt[0][j][wv] = (u32)__popcll(rm[j]); wcnt[1][j][wv] = (u32)__popcll(bm[j]); }
+    }
+    __syncthreads();
+    const u64 off = tile_off[blockIdx.x], tot = tile_off[tiles];
+    const u64 a_small = a - (tot >> 32);                       // the larger groups' members land behind the smaller groups' (list order kept)
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        u32 rbefore = 0, bbefore = 0;
+        for (int jj = 0; jj <= j; jj++)
+            for (int w = 0; w < DG_THREADS / 64; w++)
+                if (jj < j || w < wv) { rbefore += wcnt[0][jj][w]; bbefore += wcnt[1][jj][w]; }
+        const u32 sl = (u32)j * DG_THREADS + tid;
+        if (ds.kind[j] == 1 && ds.gs[j] == sl) {
+            u32 mn = 0xffffffffu, mx = 0;
+            for (u32 m = 0; m < ds.sz[j]; m++) { const u32 q = pos[sl + m]; mn = q < mn ? q : mn; mx = q > mx ? q : mx; }
+            const u64 r = (u32)off + rbefore + (u32)__popcll(rm[j] & lanemask_lt());
+            if (pairs && ds.sz[j] == 2) {
+                // a group of two travels whole: (larger position << 32 | smaller position, head) -- its members need not be fetched again
+                rkeys[r] = ((u64)mx << 32) | mn;
+                rvals[r] = ds.h[j];
+            } else {
+                rkeys[r] = ((u64)((pairs ? 0x80000000u : 0u) | (u32)(e0 + (long long)sl)) << 32) | mn;        // list index of the first member
+                rvals[r] = ds.sz[j];
+            }
+        }
+        if (ds.kind[j] == 2) {
+            const u64 o = a_small + (off >> 32) + bbefore + (u32)__popcll(bm[j] & lanemask_lt());
+            st_idx[o] = ds.idx[j];
+            st_head[o] = ds.h[j];
+        }
+    }
+}
+// record forms (go_write_kernel): pairs == false: (list index of the first member << 32 | smallest position, size); pairs == true:
+// bit 63 set: the same with the flag; bit 63 clear: a group of two, (larger position << 32 | smaller position, head)
+struct GoSizeIn {
+    const u64 *rk; const u32 *rv; bool pairs;
+    __device__ __forceinline__ u32 operator()(u64 j) const { return (pairs && !(rk[j] >> 63)) ? 2u : rv[j]; }
+};
+// members of the sorted groups to their places: a pair comes out of its record; of the others a lane copies its own group when it is
+// short, the wave together the longer ones (two scattered reads per group: the list is in SA order)
+__global__ __launch_bounds__(256) void go_expand_kernel(const u64 *__restrict__ rkeys, const u32 *__restrict__ rvals, const u32 *__restrict__ doff, u64 groups,
+                                                        const u32 *__restrict__ idx, const u32 *__restrict__ head, u32 *__restrict__ st_idx, u32 *__restrict__ st_head,
+                                                        bool pairs)
+{
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    const int lane = lane_id();
+    u32 e = 0, sz = 0, d = 0;
+    if (j < groups) {
+        const u64 k = rkeys[j];
+        const u32 v = rvals[j];
+        d = doff[j];
+        if (pairs && !(k >> 63)) {
+            st_idx[d] = (u32)k; st_idx[d + 1] = (u32)(k >> 32);
+            st_head[d] = v; st_head[d + 1] = v;
+        } else { e = (u32)(k >> 32) & (pairs ? 0x7fffffffu : 0xffffffffu); sz = v; }
+    }
+    if (sz && sz <= 4) {
+        u32 pi[4], ph[4];
+#pragma unroll
+        for (u32 t = 0; t < 4; t++) { pi[t] = t < sz ? idx[e + t] : 0u; ph[t] = t < sz ? head[e + t] : 0u; }
+#pragma unroll
+        for (u32 t = 0; t < 4; t++) if (t < sz) { st_idx[d + t] = pi[t]; st_head[d + t] = ph[t]; }
+    }
+    u64 longm = __ballot(sz > 4);
+    while (longm) {
+        const int r = __ffsll((unsigned long long)longm) - 1;
+        longm &= longm - 1;
+        const u32 re = shfl_t(e, r), rs = shfl_t(sz, r), rd = shfl_t(d, r);
+        for (u32 t = (u32)lane; t < rs; t += 64) { st_idx[rd + t] = idx[re + t]; st_head[rd + t] = head[re + t]; }
+    }
 }
 
 // ---- the big list ---------------------------------------------------------------------------------------------------------
@@ -551,34 +659,52 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     PrevSym prev{sp.carry_src, d_T, n, d_fstart, k};
     u8 *out = CYCLIC ? sp.carry_out : nullptr;
     u32 rounds = *rounds_io;
-    // order key of a list element: (group head << kb) | smallest position of the group (n + head for the larger groups), kb a whole
-    // number of radix digits so that the sort on the low kb bits orders by that field alone
-    const int kb0 = bitlen_u64(2 * n - 1), kb = kb0 > 32 ? kb0 : (kb0 + 7) / 8 * 8, sort_bits = kb > 32 ? 32 : kb;
 
-    // ---- one-off order: groups by their smallest position, the larger groups behind all others (dg_minpos_kernel) ----
+    // ---- one-off order: group records sorted by the group's smallest position, members copied to their places; the larger groups'
+    // members compacted behind them (see go_write_kernel) ----
     u64 a_small = 0;
     {
-        SortPlan op;
-        op.keys[0] = (u64 *)ob; op.keys[1] = (u64 *)(ob + e8);
-        op.vals[0] = (u32 *)(ob + 2 * e8); op.vals[1] = (u32 *)(ob + 2 * e8 + e4);
-        op.tile_hist = sp.tile_hist; op.scan_temp = sp.scan_temp;
+        const u64 tiles = (a0 + DG_OWN - 1) / DG_OWN;
+        const bool pairs = n <= 0x80000000ull;                        // (positions and list indices below 2^31)
+        const u64 gmax = a0 / 2 + 1;                                  // a group has at least two members
+        const size_t g8 = align_up((size_t)gmax * 8, 256), g4 = align_up((size_t)gmax * 4, 256);
+        // records and their sort buffers inside the order block (2 x 8 + 3 x 4 bytes per group <= 14 bytes per element), tile counts behind
+        u64 *rk[2] = {(u64 *)ob, (u64 *)(ob + g8)};
+        u32 *rv[2] = {(u32 *)(ob + 2 * g8), (u32 *)(ob + 2 * g8 + g4)};
+        u32 *doff = (u32 *)(ob + 2 * g8 + 2 * g4);
+        u64 *tcount = (u64 *)(ob + 2 * g8 + 3 * g4);
+        if (2 * g8 + 3 * g4 + align_up((size_t)(tiles + 1) * 8, 256) > 2 * e8 + 2 * e4) CH_FAIL("order block too small");
         {
-            SpanGuard g(ctx, BWTS_K_RERANK, a0, 20 * a0);
-            dg_minpos_kernel<<<dim3((unsigned)((a0 + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a0, n, kb, op.keys[0], op.vals[0]);
-            CH_HIP(hipGetLastError());
-        }
-        int ores = 0;
-        CH_TRY(radix_sort_pairs(ctx, op, a0, sort_bits, &ores));
-        {
-            SpanGuard g(ctx, BWTS_K_RERANK, a0, 20 * a0);
-            dg_unpack_kernel<<<dim3((unsigned)((a0 + 255) / 256)), dim3(256), 0, ctx->stream>>>(op.keys[ores], op.vals[ores], a0, kb, st_idx, st_head);
-            chunk_find_big_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(op.keys[ores], a0, sort_bits, kb > 32 ? n >> (kb - 32) : n,
-                                                                        (unsigned long long *)(slots + CHS_TOTAL));
+            SpanGuard g(ctx, BWTS_K_RERANK, a0, 14 * a0);
+            go_count_kernel<<<dim3((unsigned)tiles), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a0, tcount);
+            CH_HIP(hipMemsetAsync(tcount + tiles, 0, sizeof(u64), ctx->stream));
+            ScanLoadArr<u64> tin{tcount};
+            ScanStoreArr<u64> tout{tcount};
+            CH_TRY((device_scan<false, u64>(ctx, tiles + 1, tin, tout, OpAdd(), (u64)0, sp.scan_temp)));
+            CH_HIP(hipMemcpyAsync(slots + CHS_TOTAL, tcount + tiles, sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+            go_write_kernel<<<dim3((unsigned)tiles), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a0, tcount, tiles, rk[0], rv[0], st_idx, st_head, pairs);
             CH_HIP(hipGetLastError());
         }
         CH_TRY(read_small(ctx, SM_CHSLOT, CH_SLOT_WORDS));
-        a_small = ctx->h_small[SM_CHSLOT + CHS_TOTAL];
-        if (a_small > a0) CH_FAIL("boundary of the larger groups");
+        const u64 tot = ctx->h_small[SM_CHSLOT + CHS_TOTAL];
+        const u64 groups = (u32)tot, bigs = tot >> 32;
+        if (bigs > a0 || groups > gmax) CH_FAIL("group records");
+        a_small = a0 - bigs;
+        if (groups) {
+            SortPlan op;
+            op.keys[0] = rk[0]; op.keys[1] = rk[1];
+            op.vals[0] = rv[0]; op.vals[1] = rv[1];
+            op.tile_hist = sp.tile_hist; op.scan_temp = sp.scan_temp;
+            int ores = 0;
+            const int pb = bitlen_u64(n - 1);
+            CH_TRY(radix_sort_pairs(ctx, op, groups, pb < 1 ? 1 : pb, &ores));
+            SpanGuard g(ctx, BWTS_K_RERANK, a_small, 20 * a_small);
+            GoSizeIn zin{rk[ores], rv[ores], pairs};
+            ScanStoreArr<u32> zout{doff};
+            CH_TRY((device_scan<false, u32>(ctx, groups, zin, zout, OpAdd(), 0u, sp.scan_temp)));
+            go_expand_kernel<<<dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream>>>(rk[ores], rv[ores], doff, groups, cur.idx, cur.head, st_idx, st_head, pairs);
+            CH_HIP(hipGetLastError());
+        }
     }
     u64 m_big = a0 - a_small;
     if (round_trace) fprintf(stderr, "[chunks] list %llu: in chunks %llu (nominal chunk %u), big list %llu\n", (unsigned long long)a0,
