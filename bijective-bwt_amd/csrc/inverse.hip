@@ -199,15 +199,13 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
     __shared__ u64 Ctab[257];
     extern __shared__ __attribute__((aligned(16))) unsigned long long walk_mom_sm[];     // MARK_MOMENTS: 2^mom_shift sums, sums of squares, counts
     const u32 mom_classes = MARK == MARK_MOMENTS ? 1u << mom_shift : 0u;
-    // per class: (count << 43 | sum of quotients) in one word -- one LDS atomic for both (a class holds at most 2^20 indices with
-    // quotients below 2^22) -- and the sum of squares
-    unsigned long long *mcs = walk_mom_sm, *msq = walk_mom_sm + mom_classes;
-    if (MARK == MARK_MOMENTS) for (u32 b = threadIdx.x; b < mom_classes; b += 256) { mcs[b] = 0; msq[b] = 0; }
-    // the next LF entry is fetched as soon as its index is known -- before the symbol search, the moments and the recording of
-    // the current step -- so a step costs the longer of the memory round trip and that work, not their sum (speculative at a
-    // segment's last step: one wasted read in G)
-    constexpr bool PREFETCH = MARK == MARK_MOMENTS;
-    u32 ypre = 0;
+    unsigned long long *msum = walk_mom_sm, *msq = walk_mom_sm + mom_classes;
+    u32 *mcnt = (u32 *)(walk_mom_sm + 2 * mom_classes);
+    if (MARK == MARK_MOMENTS) for (u32 b = threadIdx.x; b < mom_classes; b += 256) { mcnt[b] = 0; msum[b] = 0; msq[b] = 0; }
+    // (Round 3 tried two things here and measured both worse: fetching the next LF entry before the current step's symbol search and
+    // moments -- the walk is bound by the memory system's line-fill rate, not by a lane's dependency chain, and the second read in
+    // flight per lane only lengthens the queues: dna 2^32 119.7 -> 129.5 ms, zipf 2^30 27.4 -> 27.8 ms -- and count + sum in one
+    // 64-bit LDS atomic, which changed nothing measurable.  tools/sessions/r03y.sh, r03af.sh.)
     // MARK_LOG: how many indices of each 2^IDX_RANGE_LOG2-range this workgroup visited.  A range that ends up with all of
     // its indices counted holds nothing unvisited, and its log entries need not be looked at again.
     __shared__ u32 bseen[MARK == MARK_LOG ? IDX_MAX_BUCKETS : 1];
@@ -252,7 +250,6 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                 const u64 id = bnext + (u64)__popcll(need & lanemask_lt());
                 if (id < bend) {
                     have = true; my = id; x = (u32)(my << g); len = 0; mn = x; mnoff = 0;
-                    if (PREFETCH) ypre = LF[x];
 #pragma unroll
                     for (int q = 0; q < SBW; q++) sb[q] = 0;
                 }
@@ -283,15 +280,13 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
                 lcur += na;
             }
         }
-        u32 ynext = 0;
-        if (PREFETCH && have) ynext = LF[ypre];
         if (MARK == MARK_MOMENTS && have) {
             const u32 b = x & (mom_classes - 1u);                           // classes by the low bits: the unreached elements of real inputs cluster in rank
             const unsigned long long o = x >> mom_shift;
-            atomicAdd(&mcs[b], (1ull << 43) + o); atomicAdd(&msq[b], o * o);
+            atomicAdd(&mcnt[b], 1u); atomicAdd(&msum[b], o); atomicAdd(&msq[b], o * o);
         }
         if (have) {
-            const u32 y = PREFETCH ? ypre : LF[x];
+            const u32 y = LF[x];
             if (MARK == MARK_BYTEMAP) marks[x] = 1;
             else if (MARK == MARK_SENTINEL) LF[x] = LF_VISITED;       // the entry is not needed again
             {
@@ -309,7 +304,6 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
             }
             len++;
             x = y;
-            if (PREFETCH) ypre = ynext;
             const bool at_splitter = (x & gmask) == 0;
             if (at_splitter || len == slot) {
                 if (len & SBM) {                                                                             // slot is a multiple of 16
@@ -343,8 +337,8 @@ __global__ __launch_bounds__(256) void walk_record_kernel(u32 *__restrict__ LF, 
     if (MARK == MARK_MOMENTS) {
         __syncthreads();
         for (u32 b = threadIdx.x; b < mom_classes; b += 256) {
-            const unsigned long long cs = mcs[b];
-            if (cs) { atomicAdd(&mom[b], cs >> 43); atomicAdd(&mom[mom_classes + b], cs & ((1ull << 43) - 1ull)); atomicAdd(&mom[2 * mom_classes + b], msq[b]); }
+            const u32 c = mcnt[b];
+            if (c) { atomicAdd(&mom[b], (unsigned long long)c); atomicAdd(&mom[mom_classes + b], msum[b]); atomicAdd(&mom[2 * mom_classes + b], msq[b]); }
         }
     }
 #ifdef WALK_PROFILE
