@@ -235,6 +235,24 @@ def test_dense_rounds_repeated_material(ctx, kind):
     assert np.array_equal(ctx.inverse(y), x)
 
 
+def test_chunk_rounds_many_factors_equal_rotations(ctx):
+    """More Lyndon factors than the chunk kernel keeps in LDS (its general-arithmetic instantiation), every factor there twice: all
+    positions stay tied to the end (equal rotations of equal factors), so the rounds stop on "no group split" and the leftover groups are
+    laid out by chunk_rest_kernel."""
+    rng = np.random.default_rng(4242)
+    parts = []
+    for c in range(200, -1, -1):                    # a word whose first letter is strictly its smallest is a Lyndon word; first letters fall
+        body = rng.integers(c + 1, min(c + 6, 256), size=int(rng.integers(2500, 3500)), dtype=np.uint8)
+        block = np.concatenate([np.array([c], dtype=np.uint8), body])
+        parts += [block, block]
+    x = np.concatenate(parts)
+    y = ctx.forward(x)
+    t = ctx.timings()
+    assert t.factors == 402 and t.active_after_round0 == len(x)
+    assert np.array_equal(y, O.forward(x))
+    assert np.array_equal(ctx.inverse(y), x)
+
+
 def test_dense_ties_large_vs_oracle(ctx):
     """n >= 2^22 with most elements tied after round 0: the dense rank array is built by the binned scatter."""
     block = O.generate("zipf", 1 << 21, 5)
