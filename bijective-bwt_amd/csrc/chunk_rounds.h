@@ -21,7 +21,9 @@
 #ifndef CH_THREADS
 #define CH_THREADS 512
 #endif
+#ifndef CH_ITEMS
 #define CH_ITEMS   4
+#endif
 #define CH_TILE    (CH_THREADS * CH_ITEMS)
 #define CH_CAP     DG_CAP
 #define CH_WORDS   (CH_TILE / 64)
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(DG_THREADS) void go_write_kernel(const u32 *__restr
                 rkeys[r] = ((u64)mx << 32) | mn;
                 rvals[r] = ds.h[j];
             } else {
-                rkeys[r] = ((u64)((pairs ? 0x80000000u : 0u) | (u32)(e0 + (long long)sl)) << 32) | mn;        // list index of the first member
+                rkeys[r] = ((u64)((pairs ? 0x80000000u : 0u) | ds.h[j]) << 32) | mn;        // the group's head = the SA slot of its first member
                 rvals[r] = ds.sz[j];
             }
         }
@@ -489,16 +491,17 @@ __global__ __launch_bounds__(DG_THREADS) void go_write_kernel(const u32 *__restr
         }
     }
 }
-// record forms (go_write_kernel): pairs == false: (list index of the first member << 32 | smallest position, size); pairs == true:
+// record forms (go_write_kernel): pairs == false: (head = SA slot of the first member << 32 | smallest position, size); pairs == true:
 // bit 63 set: the same with the flag; bit 63 clear: a group of two, (larger position << 32 | smaller position, head)
 struct GoSizeIn {
     const u64 *rk; const u32 *rv; bool pairs;
     __device__ __forceinline__ u32 operator()(u64 j) const { return (pairs && !(rk[j] >> 63)) ? 2u : rv[j]; }
 };
-// members of the sorted groups to their places: a pair comes out of its record; of the others a lane copies its own group when it is
-// short, the wave together the longer ones (two scattered reads per group: the list is in SA order)
+// members of the sorted groups to their places: a pair comes out of its record; the others are read from the suffix array itself -- a
+// group is the slot range [head, head + size) there, and all its members carry that head -- a lane copying its own group when it is
+// short, the wave together the longer ones (one scattered read per group)
 __global__ __launch_bounds__(256) void go_expand_kernel(const u64 *__restrict__ rkeys, const u32 *__restrict__ rvals, const u32 *__restrict__ doff, u64 groups,
-                                                        const u32 *__restrict__ idx, const u32 *__restrict__ head, u32 *__restrict__ st_idx, u32 *__restrict__ st_head,
+                                                        const u32 *__restrict__ SA, u32 *__restrict__ st_idx, u32 *__restrict__ st_head,
                                                         bool pairs)
 {
     const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -514,18 +517,18 @@ __global__ __launch_bounds__(256) void go_expand_kernel(const u64 *__restrict__ 
         } else { e = (u32)(k >> 32) & (pairs ? 0x7fffffffu : 0xffffffffu); sz = v; }
     }
     if (sz && sz <= 4) {
-        u32 pi[4], ph[4];
+        u32 pi[4];
 #pragma unroll
-        for (u32 t = 0; t < 4; t++) { pi[t] = t < sz ? idx[e + t] : 0u; ph[t] = t < sz ? head[e + t] : 0u; }
+        for (u32 t = 0; t < 4; t++) pi[t] = t < sz ? SA[(u64)e + t] : 0u;
 #pragma unroll
-        for (u32 t = 0; t < 4; t++) if (t < sz) { st_idx[d + t] = pi[t]; st_head[d + t] = ph[t]; }
+        for (u32 t = 0; t < 4; t++) if (t < sz) { st_idx[d + t] = pi[t]; st_head[d + t] = e; }
     }
     u64 longm = __ballot(sz > 4);
     while (longm) {
         const int r = __ffsll((unsigned long long)longm) - 1;
         longm &= longm - 1;
         const u32 re = shfl_t(e, r), rs = shfl_t(sz, r), rd = shfl_t(d, r);
-        for (u32 t = (u32)lane; t < rs; t += 64) { st_idx[rd + t] = idx[re + t]; st_head[rd + t] = head[re + t]; }
+        for (u32 t = (u32)lane; t < rs; t += 64) { st_idx[rd + t] = SA[(u64)re + t]; st_head[rd + t] = re; }
     }
 }
 
@@ -702,7 +705,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             GoSizeIn zin{rk[ores], rv[ores], pairs};
             ScanStoreArr<u32> zout{doff};
             CH_TRY((device_scan<false, u32>(ctx, groups, zin, zout, OpAdd(), 0u, sp.scan_temp)));
-            go_expand_kernel<<<dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream>>>(rk[ores], rv[ores], doff, groups, cur.idx, cur.head, st_idx, st_head, pairs);
+            go_expand_kernel<<<dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream>>>(rk[ores], rv[ores], doff, groups, SA, st_idx, st_head, pairs);
             CH_HIP(hipGetLastError());
         }
     }
