@@ -159,7 +159,7 @@ def _pmc_traffic(kernel_prefix, workload, log2n, source_file, per_elem=None):
             pm = json.load(open(os.path.join(ROOT, "profiles", name)))
             if not str(pm.get("workload", "zipf")).startswith(workload) or pm.get("log2n", 30) != log2n:
                 continue
-            if pm.get("kernel", "").split("<")[0] != kernel_prefix.split("<")[0]:
+            if not pm.get("kernel", "").split("<")[0].startswith(kernel_prefix.split("<")[0]):
                 continue
             if per_elem is not None and pm.get("alg_bytes_per_element") != per_elem:
                 continue

@@ -64,7 +64,7 @@ def main():
             w = sum(allk[k]["WRITE_SIZE"]["sum_KB"] for k in keys) / div
             out.update({"FETCH_SIZE_KB_reported_per_forward": f, "WRITE_SIZE_KB_reported_per_forward": w, "transforms_profiled": div,
                         "hbm_bytes_per_forward": int(2 * f * 1024 + w * 1024)})
-        json.dump(out, open(os.path.join(out_dir, "%s_pmc_traffic_%s.json" % (tag, rec)), "w"), indent=1)
+        json.dump(out, open(os.path.join(out_dir, "%s_pmc_traffic_%s_%s_2p%d.json" % (tag, rec, workload, log2n)), "w"), indent=1)
         print(rec, {k: v for k, v in out.items() if "KB" in k or "bytes" in k})
 
 
