@@ -209,6 +209,7 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->arena) (void)hipFree(ctx->arena);
     for (int i = 0; i < BWTS_AUX_SLOTS; i++) if (ctx->aux[i]) (void)hipFree(ctx->aux[i]);
+    for (char *b : ctx->tied_blk) (void)hipFree(b);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     for (Stager &sg : ctx->stg) {
@@ -259,6 +260,7 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
     ctx->tm.device_bytes = ctx->arena_cap + ctx->d_io_cap[0] + ctx->d_io_cap[1] + ctx->call_block_bytes;
     for (int i = 0; i < BWTS_AUX_SLOTS; i++) ctx->tm.device_bytes += ctx->aux_cap[i];
     ctx->tm.device_bytes += ctx->d_io_cap[2] + ctx->d_io_cap[3];
+    ctx->tm.device_bytes += ctx->tied_blk.size() * ((size_t)16 << ctx->tied_blk_lg);
     return BWTS_OK;
 }
 

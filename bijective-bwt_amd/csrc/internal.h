@@ -76,6 +76,10 @@ struct bwts_ctx {
     char  *aux[BWTS_AUX_SLOTS];
     size_t aux_cap[BWTS_AUX_SLOTS];
     size_t unv_hint;       // inverse: unreached elements seen by the previous call (sizes the first collection pass)
+    // tied list of the forward transform beyond 2^32 positions (wide_path.h): blocks of 2^tied_blk_lg (position, head) pairs, taken as the
+    // list grows and kept for the next call
+    std::vector<char *> tied_blk;
+    int tied_blk_lg = 0;
 
     // small pinned host block for read-backs, and a device mirror
     u64 *h_small;          // 4096 u64

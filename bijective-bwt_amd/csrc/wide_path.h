@@ -12,13 +12,14 @@
 //     bucket by bucket the members are collected (stable), sorted by key (the same LSD passes; the position's bits above 32
 //     ride in the byte stream that otherwise carries the emission byte), and finished: global rank = bucket base + group
 //     head into the n-entry u64 rank array, output byte written, tied elements appended to the tied list;
-//   * the tied list (small unless the input is repetitive) goes through rounds of (group, rank of the h-th cyclic successor)
-//     sorting with 64-bit ranks until no group splits.
+//   * the tied list (a few thousand elements for i.i.d. data, 70 % of the positions for text: it lives in blocks taken as it
+//     grows) goes through rounds of (group, rank of the h-th cyclic successor) sorting with 64-bit ranks until no group splits,
+//     a part of whole groups at a time, in place.
 // Memory: rank array 8 n, one segment of keys, one bucket's sort buffers: ~160 GiB at n = 12 GiB, against ~430 GiB for the
 // main path's layout.  The inverse's 64-bit form is wide_inverse.h (dispatched from inverse_device_impl).
 #define WIDE_PREFIX_BITS 12
 #define WIDE_PREFIXES    (1u << WIDE_PREFIX_BITS)
-#define WIDE_TIED_CAP    (1ull << 28)
+#define WIDE_MAX_PARTS   4096u
 
 __device__ __forceinline__ u64 factor_of64(const u64 *__restrict__ fstart, u64 k, u64 p)
 {
@@ -111,16 +112,24 @@ __global__ __launch_bounds__(256) void wide_head_prev_kernel(const u8 *__restric
     if (s >= pos0 && s < lim) segprev[s - pos0] = T[(f + 1 < k ? fstart[f + 1] : n) - 1];
 }
 
-// a sorted bucket is finished: ranks, output bytes, tied elements
+// The tied list: (position, group head) pairs in group order, held in blocks of 2^lg pairs that are taken from the device as the
+// list grows (a text of 6 GiB leaves 4.5 * 10^9 positions tied after round 0; i.i.d. data a few thousand) -- positions in a
+// block's first half, heads in its second.  The rounds rewrite it in place.
+#define WIDE_TB_MAX 64
+struct TiedList {
+    u64 *const *tab; int lg;
+    __device__ __forceinline__ u64 &pos(u64 i) const { return tab[i >> lg][i & ((1ull << lg) - 1ull)]; }
+    __device__ __forceinline__ u64 &head(u64 i) const { return tab[i >> lg][(1ull << lg) + (i & ((1ull << lg) - 1ull))]; }
+};
+
+// a sorted bucket is finished: ranks, output bytes, tied elements (appended from list slot tbase on: the host has made room)
 template <bool CARRY>
 __global__ __launch_bounds__(256) void wide_bucket_finish_kernel(const u64 *__restrict__ K, const u32 *__restrict__ V, const u8 *__restrict__ S, u64 m, u64 base,
                                                                  const u64 *__restrict__ headw, const u64 *__restrict__ keepw, const u64 *__restrict__ pre,
                                                                  u64 *__restrict__ rank64, PrevSym64 prev, u8 *__restrict__ out,
-                                                                 const u64 *__restrict__ tied_count, u64 tied_cap, u64 *__restrict__ tpos, u64 *__restrict__ thead,
-                                                                 u64 *__restrict__ overflow, u64 n)
+                                                                 u64 tbase, u64 tied_cap, TiedList tl, u64 *__restrict__ overflow, u64 n)
 {
     const int lane = lane_id();
-    const u64 tbase = *tied_count;
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < ((m + 63) & ~63ull); i += (u64)gridDim.x * 256) {
         if (i >= m) continue;
         const u64 w = i >> 6;
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256) void wide_bucket_finish_kernel(const u64 *__re
         out[base + i] = CARRY ? S[i] : prev(p);
         if ((km >> lane) & 1ull) {
             const u64 t = tbase + (u64)(u32)pr + (u64)__popcll(km & lanemask_lt());
-            if (t < tied_cap) { tpos[t] = p; thead[t] = r; }
+            if (t < tied_cap) { tl.pos(t) = p; tl.head(t) = r; }
             else *overflow = 1;
         }
     }
@@ -147,32 +156,66 @@ __global__ void wide_add_tied_kernel(const u64 *__restrict__ keepw, const u64 *_
 }
 
 // ---- rounds over the tied list (64-bit ranks) -------------------------------------------------------------------------
+// A round takes the list in PARTS: whole groups, as many as the sort buffers hold.  Groups are independent within a round, and a
+// rank that an earlier part has already refined is as good a sort key as the one the round started with -- better: every rank
+// ever written is the element's position in an order that the true order refines, and equal ranks mean "tied so far", so a
+// comparison of two successors' ranks is never wrong whichever of the two states each is read in (the in-place group numbering
+// of Larsson & Sadakane's sort rests on the same fact).  A round in which no group splits changed no rank, so it still proves
+// that what remains are equal infinite words.  Survivors go back to the front of the list behind those of the parts before.
+__global__ __launch_bounds__(64) void wide_cuts_kernel(TiedList tl, u64 a, u64 P, u64 *__restrict__ cuts, u32 max_parts)
+{
+    // cuts[0] = number of parts (or ~0: a group larger than a part, or more parts than the table holds), cuts[1 + i] = end of part i
+    const int lane = threadIdx.x;
+    u64 lo = 0;
+    u32 np = 0;
+    while (lo < a) {
+        u64 e = a - lo > P ? lo + P : a;
+        if (e < a) {
+            // the last group start in (lo, e]
+            u64 top = e, found = 0;
+            while (top > lo) {
+                const u64 i = top - (u64)lane;
+                const bool st = top >= (u64)lane && i > lo && tl.head(i) != tl.head(i - 1);
+                const u64 m = __ballot(st);
+                if (m) { found = top - (u64)(__ffsll((unsigned long long)m) - 1); break; }
+                top = top - lo > 64 ? top - 64 : lo;
+            }
+            if (!found) { if (lane == 0) cuts[0] = ~0ull; return; }
+            e = found;
+        }
+        if (np >= max_parts) { if (lane == 0) cuts[0] = ~0ull; return; }
+        if (lane == 0) cuts[1 + np] = e;
+        np++;
+        lo = e;
+    }
+    if (lane == 0) cuts[0] = np;
+}
 struct WideOrdIn {
-    const u64 *head;
-    __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || head[i] != head[i - 1]) ? 1u : 0u; }
+    TiedList tl; u64 lo;
+    __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || tl.head(lo + i) != tl.head(lo + i - 1)) ? 1u : 0u; }
 };
 struct WideOrdOut {
-    const u64 *pos; const u64 *head; const u64 *rank64; u64 n; u64 h; const u64 *fstart; u64 k; int rb; u64 *bk; u32 *bv; u64 a; u64 *groups;
+    TiedList tl; u64 lo; const u64 *rank64; u64 n; u64 h; const u64 *fstart; u64 k; int rb; u64 *bk; u32 *bv; u64 m; u64 *groups;
     __device__ __forceinline__ void operator()(u64 i, u32 before) const
     {
-        const u32 st = (i == 0 || head[i] != head[i - 1]) ? 1u : 0u;
+        const u32 st = (i == 0 || tl.head(lo + i) != tl.head(lo + i - 1)) ? 1u : 0u;
         const u64 ord = (u64)before + st - 1;
-        const u64 r2 = rank64[cyclic_successor64(fstart, k, n, pos[i], h)];
+        const u64 r2 = rank64[cyclic_successor64(fstart, k, n, tl.pos(lo + i), h)];
         bk[i] = (ord << rb) | r2;
         bv[i] = (u32)i;
-        if (i + 1 == a) *groups = (u64)before + st;
+        if (i + 1 == m) *groups = (u64)before + st;
     }
 };
 struct WideRegroupOut {
-    const u64 *bk; const u32 *bv; u64 m; const u64 *pos; const u64 *head; u64 *npos; u64 *nhead; u8 *state; PrevSym64 prev; u8 *out; u64 *split;
+    const u64 *bk; const u32 *bv; u64 m; TiedList tl; u64 lo; u64 *npos; u64 *nhead; u8 *state; PrevSym64 prev; u8 *out; u64 *split;
     __device__ __forceinline__ void operator()(u64 j, u64 v) const       // inclusive scan value of DgRegroupIn
     {
         const u32 gidx = (u32)(v >> 32) - 1u, sidx = (u32)v - 1u;
         const u64 kj = bk[j];
         const bool alone = sidx == (u32)j && (j + 1 == m || bk[j + 1] != kj);
-        const u32 li = bv[j];
-        const u64 p = pos[li];
-        const u64 nh = head[li] + (u64)(sidx - gidx);
+        const u64 li = lo + (u64)bv[j];
+        const u64 p = tl.pos(li);
+        const u64 nh = tl.head(li) + (u64)(sidx - gidx);
         npos[j] = p; nhead[j] = nh;
         state[j] = (u8)((alone ? DG_DONE : DG_KEEP) | (sidx != gidx ? DG_MOVED : 0));
         if (alone) out[nh] = prev(p);
@@ -187,29 +230,61 @@ struct WideKeepIn {
     __device__ __forceinline__ u32 operator()(u64 i) const { return (state[i] & 3) == DG_KEEP ? 1u : 0u; }
 };
 struct WideKeepOut {
-    const u8 *state; const u64 *npos; const u64 *nhead; u64 *rank64; u64 *opos; u64 *ohead; u64 a; u64 *count;
+    const u8 *state; const u64 *npos; const u64 *nhead; u64 *rank64; TiedList tl; const u64 *wp; u64 m; u64 *count;
     __device__ __forceinline__ void operator()(u64 j, u32 before) const
     {
         const u32 st = state[j];
         const bool keep = (st & 3) == DG_KEEP;
         if (st & DG_MOVED) rank64[npos[j]] = nhead[j];
-        if (keep) { opos[before] = npos[j]; ohead[before] = nhead[j]; }
-        if (j + 1 == a) *count = (u64)before + (keep ? 1u : 0u);
+        if (keep) { const u64 o = *wp + (u64)before; tl.pos(o) = npos[j]; tl.head(o) = nhead[j]; }
+        if (j + 1 == m) *count = (u64)before + (keep ? 1u : 0u);
     }
 };
+__global__ void wide_advance_kernel(u64 *__restrict__ wp, const u64 *__restrict__ count)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *wp += *count;
+}
 struct WideRestIn {
-    const u64 *head;
-    __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || head[i] != head[i - 1]) ? (u32)i + 1u : 0u; }
+    TiedList tl; u64 lo;
+    __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || tl.head(lo + i) != tl.head(lo + i - 1)) ? (u32)i + 1u : 0u; }
 };
 struct WideRestOut {
-    const u64 *pos; const u64 *head; PrevSym64 prev; u8 *out;
-    __device__ __forceinline__ void operator()(u64 i, u32 v) const { out[head[i] + ((u64)i - (u64)(v - 1u))] = prev(pos[i]); }
+    TiedList tl; u64 lo; PrevSym64 prev; u8 *out;
+    __device__ __forceinline__ void operator()(u64 i, u32 v) const { out[tl.head(lo + i) + ((u64)i - (u64)(v - 1u))] = prev(tl.pos(lo + i)); }
 };
 
-struct WideKnobs { int seg_log2; u64 bucket_cap; };
+// room for `elements` list entries; the block table goes to the device whenever it has changed (or `push` asks)
+static int wide_tied_ensure(bwts_ctx *ctx, u64 elements, int lg, u64 **d_tab, bool push)
+{
+    if (!ctx->tied_blk.empty() && lg > ctx->tied_blk_lg) {
+        // (blocks of an earlier, smaller call: nothing in them is live)
+        HIPC(hipStreamSynchronize(ctx->stream));
+        for (char *b : ctx->tied_blk) HIPC(hipFree(b));
+        ctx->tied_blk.clear();
+    }
+    if (ctx->tied_blk.empty()) { ctx->tied_blk.reserve(WIDE_TB_MAX); if (lg > ctx->tied_blk_lg) ctx->tied_blk_lg = lg; }
+    const int L = ctx->tied_blk_lg;
+    const u64 want = (elements + (1ull << L) - 1ull) >> L;
+    if (want > WIDE_TB_MAX) return BWTS_E_NOMEM;
+    while (ctx->tied_blk.size() < want) {
+        const double t0 = wall_ms();
+        void *p = nullptr;
+        if (hipMalloc(&p, (size_t)16 << L) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+        ctx->tied_blk.push_back((char *)p);
+        ctx->host_ms[BWTS_H_ARENA_ALLOC] += wall_ms() - t0;
+        push = true;
+    }
+    if (push && !ctx->tied_blk.empty())
+        HIPC(hipMemcpyAsync(d_tab, ctx->tied_blk.data(), ctx->tied_blk.size() * sizeof(char *), hipMemcpyHostToDevice, ctx->stream));
+    return BWTS_OK;
+}
+
+struct WideKnobs { int seg_log2; u64 bucket_cap; u64 part; int tblock_log2; };
 static WideKnobs wide_knobs(const bwts_ctx *ctx)
 {
-    WideKnobs kn{30, 1ull << 30};
+    WideKnobs kn{30, 1ull << 30, 0, 0};
+    if (const char *e = bwts_knob(ctx, "BWTS_WIDE_PART")) { const long long v = atoll(e); if (v >= 64) kn.part = (u64)v; }             // elements per part of a round
+    if (const char *e = bwts_knob(ctx, "BWTS_WIDE_TBLOCK_LOG2")) { const int v = atoi(e); if (v >= 6 && v <= 30) kn.tblock_log2 = v; } // tied-list block size
     if (const char *e = bwts_knob(ctx, "BWTS_WIDE_SEG_LOG2")) { const int v = atoi(e); if (v >= 11 && v <= 31) kn.seg_log2 = v; }      // >= log2(KB_TILE)
     if (const char *e = bwts_knob(ctx, "BWTS_WIDE_BUCKET")) { const long long v = atoll(e); if (v >= 256 && v <= 0xff000000ll) kn.bucket_cap = (u64)v; }
     return kn;
@@ -229,8 +304,10 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     const u64 nseg = (n + seg - 1) / seg;
     const u64 tiles = scan_tiles(n);
     const u64 M = kn.bucket_cap;                                   // elements a bucket may hold
-    const u64 tied_cap = n < WIDE_TIED_CAP ? n : WIDE_TIED_CAP;    // elements the tied list may hold
-    const u64 Mb = M > tied_cap ? M : tied_cap;                    // the buckets' sort buffers also serve the rounds over the tied list
+    // the buckets' sort buffers also serve the rounds over the tied list, which take it in parts of half a buffer (the other half
+    // holds the part's regrouped elements): short inputs (the forced runs of the tests) keep room for the whole list in one part
+    const u64 whole = 2 * n < (1ull << 29) ? 2 * n : (1ull << 29);
+    const u64 Mb = M > whole ? M : whole;
     const u64 mwords = (Mb + 63) / 64 + 1;
     u64 sort_max = Mb > seg ? Mb : seg;                            // largest sort or scan through tile_hist / scan_temp:
     if (sort_max < LYN_CAND_CAP) sort_max = LYN_CAND_CAP;          // a bucket, a segment, or the factor candidates
@@ -238,7 +315,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     const size_t need = align_up(n * 8, 256) + align_up(seg * 8, 256) + align_up(seg, 256) + align_up((tiles + 1) * 8, 256) + scan_temp_bytes(n) +
                         2 * align_up(Mb * 8, 256) + 2 * align_up(Mb * 4, 256) + 4 * align_up(Mb, 256) + radix_tile_hist_bytes(sort_max) +
                         scan_temp_bytes(sort_max) + 3 * align_up(mwords * 8, 256) + 8 * align_up(LYN_CAND_CAP * 8, 256) +
-                        align_up(nseg * WIDE_PREFIXES * 4, 256) + (1 << 16);
+                        align_up(nseg * WIDE_PREFIXES * 4, 256) + align_up((WIDE_MAX_PARTS + 2) * 8, 256) + (1 << 16);
     BWTS_TRY(arena_reserve(ctx, need));
     u64 *rank64 = arena_array<u64>(ctx, n);
     u64 *segkeys = arena_array<u64>(ctx, seg);
@@ -255,6 +332,9 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     u32 *cvals[2] = {arena_array<u32>(ctx, LYN_CAND_CAP), arena_array<u32>(ctx, LYN_CAND_CAP)};
     u64 *fstart = arena_array<u64>(ctx, LYN_CAND_CAP);
     u32 *d_hist = arena_array<u32>(ctx, nseg * WIDE_PREFIXES);
+    u64 *d_cuts = arena_array<u64>(ctx, WIDE_MAX_PARTS + 2);
+    u64 **d_tab = (u64 **)arena_array<u64>(ctx, WIDE_TB_MAX);
+    if (!d_cuts || !d_tab) return BWTS_E_NOMEM;
     if (!rank64 || !segkeys || !segprev || !tile_min || !pre_temp || !bk[1] || !bv[1] || !bs_src || !bs_buf[1] || !bs_fin || !tile_hist || !scan_temp ||
         !headw || !keepw || !prew || !cand[1] || !cvals[1] || !fstart || !d_hist)
         return BWTS_E_NOMEM;
@@ -400,15 +480,14 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
         cut.push_back(nprefix);
     }
 
-    // ---- tied list (aux) -------------------------------------------------------------------------------------------------
-    char *tb = nullptr;
-    const size_t t8 = align_up((size_t)tied_cap * 8, 256);
-    BWTS_TRY(aux_reserve(ctx, 6 * t8 + align_up((size_t)tied_cap, 256), &tb));
-    u64 *tpos[2] = {(u64 *)tb, (u64 *)(tb + t8)}, *thead[2] = {(u64 *)(tb + 2 * t8), (u64 *)(tb + 3 * t8)};
-    u64 *npos = (u64 *)(tb + 4 * t8), *nhead = (u64 *)(tb + 5 * t8);
-    u8 *tstate = (u8 *)(tb + 6 * t8);
+    // ---- tied list: blocks taken as it grows ---------------------------------------------------------------------------------
+    int tlg = kn.tblock_log2;
+    if (!tlg) { tlg = bitlen_u64(n - 1); if (tlg < 8) tlg = 8; if (tlg > 28) tlg = 28; }
+    BWTS_TRY(wide_tied_ensure(ctx, 1, tlg, d_tab, true));
+    TiedList tl{d_tab, ctx->tied_blk_lg};
     u64 *d_tied = cnt + 24, *d_over = cnt + 25;
     HIPC(hipMemsetAsync(cnt + 24, 0, 2 * sizeof(u64), ctx->stream));
+    u64 tied_total = 0;
 
     // ---- bucket by bucket ----------------------------------------------------------------------------------------------------
     u64 base = 0;
@@ -448,16 +527,23 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
             ScanStoreArr<u64> wout{prew};
             BWTS_TRY((device_scan<false, u64>(ctx, words, win, wout, OpHeadCount(), (u64)0, scan_temp)));
         }
+        // the bucket's tied elements are counted before they are written: the list takes another block when they need one
+        wide_add_tied_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(keepw, prew, words, d_tied);
+        HIPC(hipGetLastError());
+        BWTS_TRY(read_small(ctx, SM_COUNTERS + 24, 1));
+        const u64 tied_before = tied_total;
+        tied_total = ctx->h_small[SM_COUNTERS + 24];
+        if (tied_total < tied_before || tied_total - tied_before > m) return BWTS_E_INTERNAL;
+        BWTS_TRY(wide_tied_ensure(ctx, tied_total ? tied_total : 1, tlg, d_tab, false));
         {
             SpanGuard g(ctx, BWTS_K_EMIT, m, 15 * m);
             u64 blocks = (m + 255) / 256; if (blocks > 16384) blocks = 16384;
             if (carry)
                 wide_bucket_finish_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], sp.vals[res], bs_fin, m, base, headw, keepw, prew,
-                                                                                                      rank64, prev, d_out, d_tied, tied_cap, tpos[0], thead[0], d_over, n);
+                                                                                                      rank64, prev, d_out, tied_before, tied_total, tl, d_over, n);
             else
                 wide_bucket_finish_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], sp.vals[res], bs_fin, m, base, headw, keepw, prew,
-                                                                                                       rank64, prev, d_out, d_tied, tied_cap, tpos[0], thead[0], d_over, n);
-            wide_add_tied_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(keepw, prew, words, d_tied);
+                                                                                                       rank64, prev, d_out, tied_before, tied_total, tl, d_over, n);
             HIPC(hipGetLastError());
         }
         base += m;
@@ -466,55 +552,92 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     BWTS_TRY(read_small(ctx, SM_COUNTERS + 24, 2));
     u64 a = ctx->h_small[SM_COUNTERS + 24];
     if (ctx->h_small[SM_COUNTERS + 25] == 2) return BWTS_E_INTERNAL;              // a sorted element carried a position outside the text
-    if (ctx->h_small[SM_COUNTERS + 25] || a > tied_cap) return BWTS_E_NOMEM;      // more tied elements than the tied list holds
+    if (ctx->h_small[SM_COUNTERS + 25] || a != tied_total) return BWTS_E_INTERNAL; // (the list had room for every count read above)
     ctx->tm.active_after_round0 = a;
     ctx->tm.round_active[0] = a;
 
-    // ---- rounds over the tied list ---------------------------------------------------------------------------------------
+    // ---- rounds over the tied list, part by part ----------------------------------------------------------------------------
     u32 rounds = 1;
     const int rb = bitlen_u64(n - 1);
-    int cur = 0;
+    u64 P = kn.part ? kn.part : Mb / 2;
+    if (P > Mb / 2) P = Mb / 2;
+    while (P > 64 && bitlen_u64(P / 2) + rb > 64) P >>= 1;       // (group ordinal, rank) must fit a 64-bit sort key
+    u64 *npos = bk[0] + (Mb - Mb / 2), *nhead = bk[1] + (Mb - Mb / 2);       // the buffers' second halves
+    u8 *tstate = bs_src;
+    u64 *d_wp = cnt + 26, *d_cnt = cnt + 0, *d_split = cnt + 1, *d_groups = cnt + 3;
+    std::vector<u64> h_cuts(WIDE_MAX_PARTS + 2);
+    auto cut_parts = [&](u64 count, u64 *nparts) -> int {
+        wide_cuts_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(tl, count, P, d_cuts, WIDE_MAX_PARTS);
+        HIPC(hipGetLastError());
+        HIPC(hipMemcpyAsync(h_cuts.data(), d_cuts, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+        if (h_cuts[0] == ~0ull) return BWTS_E_RANGE;               // a group of more elements than a part holds
+        *nparts = h_cuts[0];
+        HIPC(hipMemcpyAsync(h_cuts.data() + 1, d_cuts + 1, (size_t)*nparts * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+        return BWTS_OK;
+    };
     for (u64 h = (u64)al.hstep; a > 0; h <<= 1) {
         rounds++;
+        u64 nparts = 0;
+        BWTS_TRY(cut_parts(a, &nparts));
         HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
-        {
-            SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 36 * a);
-            WideOrdIn oin{thead[cur]};
-            WideOrdOut oout{tpos[cur], thead[cur], rank64, n, h, fstart, k, rb, bk[0], bv[0], a, cnt + 3};
-            BWTS_TRY((device_scan<false, u32>(ctx, a, oin, oout, OpAdd(), 0u, scan_temp)));
+        HIPC(hipMemsetAsync(d_wp, 0, sizeof(u64), ctx->stream));
+        u64 lo = 0;
+        for (u64 part = 0; part < nparts; part++) {
+            const u64 e = h_cuts[1 + part];
+            if (e <= lo || e > a || e - lo > P) return BWTS_E_INTERNAL;
+            const u64 m = e - lo;
+            {
+                SpanGuard g(ctx, BWTS_K_KEYBUILD, m, 36 * m);
+                WideOrdIn oin{tl, lo};
+                WideOrdOut oout{tl, lo, rank64, n, h, fstart, k, rb, bk[0], bv[0], m, d_groups};
+                BWTS_TRY((device_scan<false, u32>(ctx, m, oin, oout, OpAdd(), 0u, scan_temp)));
+            }
+            BWTS_TRY(read_small(ctx, SM_COUNTERS + 3, 1));
+            const u64 groups = ctx->h_small[SM_COUNTERS + 3];
+            if (bitlen_u64(groups) + rb > 64) return BWTS_E_RANGE;
+            SortPlan tp;
+            tp.keys[0] = bk[0]; tp.keys[1] = bk[1];
+            tp.vals[0] = bv[0]; tp.vals[1] = bv[1];
+            tp.tile_hist = tile_hist; tp.scan_temp = scan_temp;
+            int tres = 0;
+            BWTS_TRY(radix_sort_pairs(ctx, tp, m, bitlen_u64(groups) + rb, &tres));
+            {
+                SpanGuard g(ctx, BWTS_K_RERANK, m, 48 * m);
+                DgRegroupIn rin{bk[tres], m, rb};
+                WideRegroupOut rout{bk[tres], bv[tres], m, tl, lo, npos, nhead, tstate, prev, d_out, d_split};
+                BWTS_TRY((device_scan<true, u64>(ctx, m, rin, rout, OpMax2(), (u64)0, scan_temp)));
+                WideKeepIn kin{tstate};
+                WideKeepOut kout{tstate, npos, nhead, rank64, tl, d_wp, m, d_cnt};
+                BWTS_TRY((device_scan<false, u32>(ctx, m, kin, kout, OpAdd(), 0u, scan_temp)));
+                wide_advance_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(d_wp, d_cnt);
+                HIPC(hipGetLastError());
+            }
+            lo = e;
         }
+        if (lo != a) return BWTS_E_INTERNAL;
         BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
-        const u64 groups = ctx->h_small[SM_COUNTERS + 3];
-        if (bitlen_u64(groups) + rb > 64) return BWTS_E_RANGE;
-        SortPlan tp;
-        tp.keys[0] = bk[0]; tp.keys[1] = bk[1];
-        tp.vals[0] = bv[0]; tp.vals[1] = bv[1];
-        tp.tile_hist = tile_hist; tp.scan_temp = scan_temp;
-        int tres = 0;
-        BWTS_TRY(radix_sort_pairs(ctx, tp, a, bitlen_u64(groups) + rb, &tres));
-        {
-            SpanGuard g(ctx, BWTS_K_RERANK, a, 48 * a);
-            DgRegroupIn rin{bk[tres], a, rb};
-            WideRegroupOut rout{bk[tres], bv[tres], a, tpos[cur], thead[cur], npos, nhead, tstate, prev, d_out, cnt + 1};
-            BWTS_TRY((device_scan<true, u64>(ctx, a, rin, rout, OpMax2(), (u64)0, scan_temp)));
-            WideKeepIn kin{tstate};
-            WideKeepOut kout{tstate, npos, nhead, rank64, tpos[cur ^ 1], thead[cur ^ 1], a, cnt + 0};
-            BWTS_TRY((device_scan<false, u32>(ctx, a, kin, kout, OpAdd(), 0u, scan_temp)));
-        }
-        BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
-        const u64 a_new = ctx->h_small[SM_COUNTERS + 0], splits = ctx->h_small[SM_COUNTERS + 1];
+        BWTS_TRY(read_small(ctx, SM_COUNTERS + 26, 1));
+        const u64 a_new = ctx->h_small[SM_COUNTERS + 26], splits = ctx->h_small[SM_COUNTERS + 1];
         if (a_new > a) return BWTS_E_INTERNAL;
-        cur ^= 1;
         a = a_new;
         if (rounds - 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[rounds - 1] = a;
         if (a == 0 || splits == 0) break;                   // no group split: equal infinite words
         if (rounds > 80) return BWTS_E_INTERNAL;
     }
     if (a) {
-        SpanGuard g(ctx, BWTS_K_EMIT, a, 20 * a);
-        WideRestIn rin{thead[cur]};
-        WideRestOut rout{tpos[cur], thead[cur], prev, d_out};
-        BWTS_TRY((device_scan<true, u32>(ctx, a, rin, rout, OpMax(), 0u, scan_temp)));
+        u64 nparts = 0;
+        BWTS_TRY(cut_parts(a, &nparts));
+        u64 lo = 0;
+        for (u64 part = 0; part < nparts; part++) {
+            const u64 e = h_cuts[1 + part], m = e - lo;
+            SpanGuard g(ctx, BWTS_K_EMIT, m, 20 * m);
+            WideRestIn rin{tl, lo};
+            WideRestOut rout{tl, lo, prev, d_out};
+            BWTS_TRY((device_scan<true, u32>(ctx, m, rin, rout, OpMax(), 0u, scan_temp)));
+            lo = e;
+        }
     }
     ctx->tm.rounds = rounds;
     return BWTS_OK;

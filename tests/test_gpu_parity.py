@@ -652,6 +652,20 @@ for kind, n, seed in %r:
         assert np.array_equal(y, O.forward(x)), (kind, n)
         assert np.array_equal(ctx.inverse(y), x)
         print(kind, n, "rounds", t.rounds, "tied", t.active_after_round0, "factors", t.factors)
+# the rounds take the tied list in parts of whole groups and the list lives in blocks: small parts and blocks, so that a round has
+# dozens of parts, survivors cross block borders, and later parts read ranks that earlier parts of the same round refined
+for kind, n, seed, part, lg in (("text", 300007, 11, 3000, 12), ("text", (1 << 20) + 5, 12, 20000, 14), ("dna", 200003, 13, 64, 8),
+                                ("zipf", 400009, 14, 1000, 10)):
+    os.environ["BWTS_WIDE_BUCKET"] = str(max(256, n // 5))
+    os.environ["BWTS_WIDE_PART"] = str(part); os.environ["BWTS_WIDE_TBLOCK_LOG2"] = str(lg)
+    x = O.generate(kind, n, seed)
+    with pkg.Context(0) as ctx:
+        y = ctx.forward(x)
+        t = ctx.timings()
+        assert np.array_equal(y, O.forward(x)), ("parts", kind, n)
+        print("parts:", kind, n, "rounds", t.rounds, "tied", t.active_after_round0, "parts of", part, "blocks of", 1 << lg)
+        if kind == "text": assert t.active_after_round0 > 8 * part
+del os.environ["BWTS_WIDE_PART"], os.environ["BWTS_WIDE_TBLOCK_LOG2"]
 for kat in (b"banana", b"mississippi", b"abracadabra", b"the quick brown fox jumps over the lazy dog"):
     os.environ["BWTS_WIDE_BUCKET"] = "256"
     with pkg.Context(0) as ctx:
@@ -792,8 +806,18 @@ with pkg.Context(0) as ctx:
     print("wide: %%.1f ms, rounds %%d, tied %%d, factors %%d" %% (t.total_ms, t.rounds, t.active_after_round0, t.factors))
     ctx.inverse_device(b, n, c)
     assert ctx.device_equal(a, c, n)                # the main inverse turns it back into the input
+    # text(2^30): 750 M positions tied after round 0 -- the tied list in blocks, every round in three parts -- against the oracle's
+    # bytes at this size (tests/golden/big_forward.json)
+    import hashlib, json
+    gold = [r for r in json.load(open(%r))["cases"] if r["kind"] == "text" and r["n"] == n and r["seed"] == 1][0]
+    ctx.generate("text", 1, n, a)
+    ctx.forward_device(a, n, b)
+    t = ctx.timings()
+    print("wide text: %%.1f ms, rounds %%d, tied %%d, factors %%d" %% (t.total_ms, t.rounds, t.active_after_round0, t.factors))
+    assert t.active_after_round0 > n // 2
+    assert hashlib.sha256(b.download().tobytes()).hexdigest() == gold["sha256_bwts"]
 print("wide ok")
-""" % (ROOT,)
+""" % (ROOT, os.path.join(ROOT, "tests", "golden", "big_forward.json"))
     env = dict(os.environ, BWTS_TEST_CHILD="1", BWTS_TEST_KNOBS="1", BWTS_FORCE_WIDE="2", BWTS_WIDE_SEG_LOG2="27", BWTS_WIDE_BUCKET=str(1 << 27))
     proc = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
     out, _ = proc.communicate(timeout=900)
