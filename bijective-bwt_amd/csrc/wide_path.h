@@ -156,12 +156,16 @@ __global__ void wide_add_tied_kernel(const u64 *__restrict__ keepw, const u64 *_
 }
 
 // ---- rounds over the tied list (64-bit ranks) -------------------------------------------------------------------------
-// A round takes the list in PARTS: whole groups, as many as the sort buffers hold.  Groups are independent within a round, and a
-// rank that an earlier part has already refined is as good a sort key as the one the round started with -- better: every rank
-// ever written is the element's position in an order that the true order refines, and equal ranks mean "tied so far", so a
-// comparison of two successors' ranks is never wrong whichever of the two states each is read in (the in-place group numbering
-// of Larsson & Sadakane's sort rests on the same fact).  A round in which no group splits changed no rank, so it still proves
-// that what remains are equal infinite words.  Survivors go back to the front of the list behind those of the parts before.
+// A round takes the list in PARTS: whole groups, as many as the sort buffers hold.  A part gathers all its keys, sorts, regroups,
+// and only then writes the new ranks of its elements; the next part starts after that.  So whoever reads the ranks of a group's
+// members sees the group either entirely as the round found it or entirely refined, never a mixture -- which is all the
+// comparison of two successors' ranks needs (a refined group's ranks lie inside the old group's range and order its members
+// correctly; an old group's are all equal: "tied so far").  A mixture would not do: with heads as ranks, a member already
+// showing head + 1 beside a larger group-mate still showing head orders the wrong way round -- the reason the main path's round
+// kernels, whose workgroups run side by side, only read the rank array and apply the moves afterwards.  This is the order of
+// work of Larsson & Sadakane's sequential sort, a part for a group.  A round in which no group splits has changed no rank, so it
+// still proves that what remains are equal infinite words.  Survivors go back to the front of the list behind those of the
+// parts before.
 __global__ __launch_bounds__(64) void wide_cuts_kernel(TiedList tl, u64 a, u64 P, u64 *__restrict__ cuts, u32 max_parts)
 {
     // cuts[0] = number of parts (or ~0: a group larger than a part, or more parts than the table holds), cuts[1 + i] = end of part i
