@@ -58,6 +58,10 @@ const char *bwts_knob(const bwts_ctx *ctx, const char *name)
 // ------------------------------------------------------------------------------------
 // arenas
 // ------------------------------------------------------------------------------------
+// BWTS_POISON=1 (a test switch): every block handed to a transform is filled with 0xA5 first, so that a kernel which reads memory
+// nothing has written yet does so reproducibly -- whatever an earlier call or process left there -- instead of once in a blue moon
+static bool poison_on(const bwts_ctx *ctx) { const char *e = bwts_knob(ctx, "BWTS_POISON"); return e && e[0] == '1'; }
+
 int arena_reserve(bwts_ctx *ctx, size_t bytes)
 {
     bytes = align_up(bytes, 1 << 20);
@@ -71,6 +75,7 @@ int arena_reserve(bwts_ctx *ctx, size_t bytes)
         ctx->host_ms[BWTS_H_ARENA_ALLOC] += wall_ms() - t0;
     }
     ctx->arena_off = 0;
+    if (ctx->arena && poison_on(ctx)) HIPC(hipMemsetAsync(ctx->arena, 0xA5, ctx->arena_cap, ctx->stream));
     return BWTS_OK;
 }
 
@@ -99,6 +104,7 @@ int aux_reserve_slot(bwts_ctx *ctx, int slot, size_t bytes, char **base)
         ctx->host_ms[BWTS_H_ARENA_ALLOC] += wall_ms() - t0;
     }
     *base = ctx->aux[slot];
+    if (ctx->aux[slot] && poison_on(ctx)) HIPC(hipMemsetAsync(ctx->aux[slot], 0xA5, ctx->aux_cap[slot], ctx->stream));
     return BWTS_OK;
 }
 

@@ -446,6 +446,20 @@ def _wait_gpu_handle_released(pid, timeout=30.0):
     time.sleep(0.5)
 
 
+def _child_report(name, out):
+    """What a failed child run said: kept whole under gpurun_out/ (which travels back from the GPU box), head and tail in the
+    assertion message -- a child killed by the runtime (a GPU fault aborts the process) says why at the START of its dying words."""
+    text = out.decode(errors="replace")
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "child_fail_%s.log" % "".join(c if c.isalnum() else "_" for c in name)[:80]), "w") as f:
+            f.write(text)
+    except OSError:
+        pass
+    return text if len(text) <= 6000 else text[:2500] + "\n[...]\n" + text[-3500:]
+
+
 def _run_cli(args, env=None):
     """subprocess.run for the CLIs (each opens the GPU), followed by the wait above."""
     proc = subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
@@ -699,7 +713,7 @@ print("wide ok")
     proc = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
     out, _ = proc.communicate(timeout=900)
     _wait_gpu_handle_released(proc.pid)
-    assert proc.returncode == 0 and b"wide ok" in out, out.decode()[-3000:]
+    assert proc.returncode == 0 and b"wide ok" in out, _child_report("wide", out)
 
 
 def _lf_walk_matches_text(x, y, steps):
@@ -822,7 +836,7 @@ print("wide ok")
     proc = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
     out, _ = proc.communicate(timeout=900)
     _wait_gpu_handle_released(proc.pid)
-    assert proc.returncode == 0 and b"wide ok" in out, out.decode()[-3000:]
+    assert proc.returncode == 0 and b"wide ok" in out, _child_report("wide", out)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -898,6 +912,8 @@ def test_text_1GiB_golden_and_properties(ctx):
     {"BWTS_INV_MARK": "sentinel"},                    # inverse marks visited entries in place instead of logging them
     {"BWTS_BYTEMARK": "1"},                           # inverse marks in a byte map (the n = 2^32 fallback)
     {"BWTS_SPLIT_LOG2": "0"},                         # inverse: every element a splitter (plain pointer jumping)
+    {"BWTS_POISON": "1"},                             # every arena / side block filled with 0xA5 before use: nothing may read what nothing wrote
+    {"BWTS_POISON": "1", "BWTS_DENSE": "tiles"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_alternate_paths(env):
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
@@ -913,7 +929,7 @@ def test_alternate_paths(env):
         proc.kill()
         out, _ = proc.communicate()
     _wait_gpu_handle_released(proc.pid)
-    assert proc.returncode == 0, out.decode()[-3000:]
+    assert proc.returncode == 0, _child_report("alternate_" + ",".join("%s=%s" % kv for kv in env.items()), out)
 
 
 def test_stray_knobs_are_ignored_without_the_gate(pkg):
