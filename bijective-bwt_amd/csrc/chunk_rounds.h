@@ -12,10 +12,14 @@
 //     of the ranks);
 //   * the grid is one workgroup per chunk in every round and the sizes live on the device, so the host has nothing to read back
 //     between rounds except "is anything left / did anything split": once no larger group is left it enqueues two rounds per sync.
-// Groups of more than CH_CAP members never enter a chunk.  The one-off order by smallest position puts them behind all the others;
-// they form the BIG LIST, which goes through the sort-based round (gather, two radix sorts, regroup -- the larger-group path of
-// dense_rounds on a dense list), and whatever falls to CH_CAP members or fewer leaves the big list as new chunks appended behind
-// the existing ones.  Groups only ever split, so an element is appended at most once and the chunk store never outgrows the list.
+// The one-off order by smallest position covers the groups of up to CH_CAP members; the larger ones are put behind them, unordered.
+// Of those, groups of up to CH_GROUP_MAX (= a tile) members go to chunks of their own kind at once -- WIDE chunks, which a second
+// instantiation of the round kernel handles: every tile ordered by one segmented bitonic sort of the workgroup in LDS instead of
+// by counting inside each group; a WIDE chunk whose groups have all fallen to CH_CAP members or fewer is taken over by the
+// counting instantiation.  Groups of more than CH_GROUP_MAX members form the BIG LIST, which goes through the sort-based round
+// (gather, two radix sorts, regroup -- the larger-group path of dense_rounds on a dense list); whatever falls to CH_GROUP_MAX
+// members or fewer leaves it as new chunks appended behind the existing ones.  Groups only ever split, so an element is appended
+// at most once and the chunk store never outgrows the list.
 #pragma once
 
 #ifndef CH_THREADS
@@ -35,6 +39,7 @@
 #define CH_FS      256
 #endif
 // (factors whose data a workgroup keeps in LDS: natural data has a dozen or two)
+#define CH_GROUP_MAX CH_TILE             // largest group a chunk may hold (a tile of its own in a WIDE chunk)
 #define CH_MIN_LIST 65536ull            // shorter lists keep the tile form (dense_rounds)
 #define CH_SLOTS   4                    // result slots of rounds in flight
 #define CH_SLOT_WORDS 8
@@ -42,6 +47,39 @@
 enum { CHS_SPLIT = 0, CHS_ERR = 1, CHS_TOTAL = 2, CHS_EXIT = 3, CHS_STAY = 4 };
 static_assert(CH_CAP * 4 <= CH_TILE, "a tile must hold several whole groups");
 static_assert(16 + CH_SLOTS * CH_SLOT_WORDS <= DG_CNT_BIG + DG_CNT_SPREAD, "result slots live in the dense rounds' counter block");
+
+// WIDE chunks -- those that hold a group of more than CH_CAP members (up to CH_GROUP_MAX: what leaves the big list) -- are handled by a
+// second instantiation of the kernel, which orders every tile with one segmented bitonic sort of the whole workgroup over
+// (group's first slot, rank at h[, ranks at 2h and 3h], slot) instead of counting inside each group: N slots (a power of two >= the
+// tile), the slots behind the tile sort behind it.  pay = group's first slot << 16 | slot.
+template <int NKEYS>
+__device__ __forceinline__ void chunk_bitonic_sort(u32 *key, u64 *key23, u32 *pay, u32 N, int tid)
+{
+    for (u32 k = 2; k <= N; k <<= 1)
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 q = (u32)tid; q < N / 2; q += CH_THREADS) {
+                const u32 i = ((q & ~(j - 1u)) << 1) | (q & (j - 1u)), l = i | j;
+                const bool asc = (i & k) == 0;
+                const u32 ka = key[i], kb = key[l], pa = pay[i], pb = pay[l];
+                const u32 ga = pa >> 16, gb = pb >> 16;
+                bool gt;
+                if (NKEYS == 3) {
+                    const u64 xa = key23[NKEYS == 3 ? i : 0], xb = key23[NKEYS == 3 ? l : 0];
+                    gt = ga != gb ? ga > gb : ka != kb ? ka > kb : xa != xb ? xa > xb : pa > pb;
+                    if (gt == asc) { key23[NKEYS == 3 ? i : 0] = xb; key23[NKEYS == 3 ? l : 0] = xa; }
+                } else {
+                    gt = ga != gb ? ga > gb : ka != kb ? ka > kb : pa > pb;
+                }
+                if (gt == asc) { key[i] = kb; key[l] = ka; pay[i] = pb; pay[l] = pa; }
+            }
+            // a stage with j <= 64 stays inside blocks of 128 slots, and pair q belongs to block q / 64: wave w only ever touches blocks
+            // w and w + 8.  Between two such stages the wave's own order is enough; the workgroup meets only around the wider ones.
+            const u32 jn = j > 1 ? j >> 1 : k;          // the next stage's distance (k: the first stage of the next, doubled k)
+            if (j > 64 || jn > 64) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+        }
+    __syncthreads();
+}
 
 // chunk c = list slots [cstart[c], cstart[c] + ccount[c]); the region up to cstart[c + 1] (or the store's tail) is its own.
 // The kernel is bound by its VALU instructions as much as by memory (PMC on the first version: ~350 per element, VALU busy 51 %,
@@ -51,9 +89,9 @@ static_assert(16 + CH_SLOTS * CH_SLOT_WORDS <= DG_CNT_BIG + DG_CNT_SPREAD, "resu
 // modulo the length from one 16-byte LDS read (FSL: at most CH_FS factors -- natural data has a dozen or two; inputs with more
 // take the instantiation with the general 64-bit arithmetic); and a slot's group extent comes from the wave's own __ballot word
 // (which is exactly the 64 slots of its lanes) plus two per-word neighbour values, not from a bit search over LDS per lane.
-template <bool CYCLIC, int NKEYS, bool FSL /* cyclic, at most CH_FS factors: their data sits in LDS */>
-__global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u32 *idx, u32 *head, const u32 *__restrict__ cstart, u32 *__restrict__ ccount,
-                                                                 u64 *__restrict__ mv, u32 *__restrict__ mvcount,
+template <bool CYCLIC, int NKEYS, bool FSL /* cyclic, at most CH_FS factors: their data sits in LDS */, bool WIDE /* the chunks flagged in cwide, and only those */>
+__global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_round_kernel(u32 *idx, u32 *head, const u32 *__restrict__ cstart, u32 *__restrict__ ccount,
+                                                                 u8 *__restrict__ cwide, u64 *__restrict__ mv, u32 *__restrict__ mvcount,
                                                                  const u32 *__restrict__ rank, u64 n, u64 h,
                                                                  const u32 *__restrict__ fstart, u64 k,
                                                                  PrevSym prev, u8 *__restrict__ out, unsigned long long *__restrict__ result)
@@ -67,13 +105,15 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
     __shared__ uint4 ftab[FSL ? CH_FS + 1 : 1];         // per factor: start, length (mod 2^32), the steps h and 2h modulo the length
     __shared__ u32 fhm3[FSL ? CH_FS : 1];               // ... and 3h
     __shared__ u32 fdir[FSL ? 256 : 1];                 // factor that holds position b << dsh: a lookup starts there
-    __shared__ u32 s_surv, s_nmv, s_split, s_err;
+    __shared__ u32 hd2[WIDE ? CH_TILE : 1];  // (WIDE) the heads, while hd carries the sort's payload
+    __shared__ u32 s_surv, s_nmv, s_split, s_err, s_wide;
     const int tid0 = threadIdx.x;
     const u32 c = blockIdx.x;
+    if ((cwide[c] != 0) != WIDE) return;
     const u64 base = (u64)(u32)__builtin_amdgcn_readfirstlane((int)cstart[c]);
     const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)ccount[c]);
     if (cnt == 0) { if (tid0 == 0) mvcount[c] = 0; return; }
-    if (tid0 == 0) { s_nmv = 0; s_split = 0; s_err = 0; }
+    if (tid0 == 0) { s_nmv = 0; s_split = 0; s_err = 0; s_wide = 0; }
     // the step, wave-uniform.  Cyclic with the factors in LDS: per factor the step(s) reduced modulo its length (a division only
     // for factors shorter than the step: the short ones at the text's end), and a 256-entry directory over the positions' top bits
     // so that finding a position's factor is one table read and (nearly always) one comparison.  Suffixes: p + j h < n <=> p < nhj.
@@ -183,8 +223,115 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
             if (lane == 0) startm[(u32)j * (CH_THREADS / 64) + wv] = stm[j];
         }
         __syncthreads();
-        // the group the tile's last start opens may go on in the next tile: it is left for that one
+        const u64 le = lane == 63 ? ~0ull : (2ull << lane) - 1ull;       // slots of the word at or below mine
         u32 plen = len;
+        u32 dst[CH_ITEMS], newhead[CH_ITEMS];
+        bool alone[CH_ITEMS], moved[CH_ITEMS], act[CH_ITEMS];
+        u32 split_here = 0;
+        if constexpr (WIDE) {
+            // ---- every group of the tile ordered by one segmented sort of the workgroup ----
+            if (!final_tile) {
+                int w = CH_WORDS - 1;
+                u64 m = startm[w];
+                while (m == 0 && w > 0) { w--; m = startm[w]; }
+                plen = (u32)w * 64u + 63u - (u32)__clzll((long long)m);
+            }
+            plen = (u32)__builtin_amdgcn_readfirstlane((int)plen);
+            if (plen == 0) {
+                // one group fills the tile: it ends exactly here (the next slot shows another head), or it is too large to be in a chunk
+                if (head[base + rp + len] != hd[0]) plen = len;
+                else { if (tid == 0) s_err = 1; break; }
+            }
+            u32 N = 64; while (N < plen) N <<= 1;
+            // every slot's group: the last start at or below it
+            u32 gsl[CH_ITEMS];
+#pragma unroll
+            for (int j = 0; j < CH_ITEMS; j++) {
+                const u32 sl = (u32)j * CH_THREADS + tid;
+                gsl[j] = 0;
+                if (sl < plen) {
+                    u32 w = (u32)j * (CH_THREADS / 64) + wv;
+                    u64 m = stm[j] & le;
+                    while (m == 0ull) { w--; m = startm[w]; }          // (slot 0 starts a group: the walk ends)
+                    gsl[j] = w * 64u + 63u - (u32)__clzll((long long)m);
+                }
+            }
+            __syncthreads();                            // (every read of the heads in hd and of the start words is done)
+#pragma unroll
+            for (int j = 0; j < CH_ITEMS; j++) {
+                const u32 sl = (u32)j * CH_THREADS + tid;
+                hd2[WIDE ? sl : 0] = myh[j];
+                if (sl < N) {
+                    const bool real = sl < plen;
+                    key[sl] = real ? my_key[j] : 0xffffffffu;
+                    if (NKEYS == 3) key23[NKEYS == 3 ? sl : 0] = real ? my_key23[NKEYS == 3 ? j : 0] : ~0ull;
+                    hd[sl] = ((real ? gsl[j] : 0xffffu) << 16) | sl;
+                }
+            }
+            __syncthreads();
+            chunk_bitonic_sort<NKEYS>(key, key23, hd, N, tid);
+            // sorted slot t of this thread: whose element, which group, does a run of equal keys start / end here?
+            bool rstart[CH_ITEMS], rend[CH_ITEMS];
+            u32 src[CH_ITEMS], gst[CH_ITEMS];
+            u64 rsm[CH_ITEMS];
+#pragma unroll
+            for (int j = 0; j < CH_ITEMS; j++) {
+                const u32 t = (u32)j * CH_THREADS + tid;
+                rstart[j] = true; rend[j] = true; src[j] = 0; gst[j] = 0;
+                if (t < plen) {
+                    const u32 pt = hd[t], kt = key[t];
+                    const u64 xt = NKEYS == 3 ? key23[NKEYS == 3 ? t : 0] : 0ull;
+                    gst[j] = pt >> 16; src[j] = pt & 0xffffu;
+                    if (t > gst[j]) rstart[j] = key[t - 1] != kt || (NKEYS == 3 && key23[NKEYS == 3 ? t - 1 : 0] != xt);
+                    if (t + 1 < plen && (hd[t + 1] >> 16) == gst[j]) rend[j] = key[t + 1] != kt || (NKEYS == 3 && key23[NKEYS == 3 ? t + 1 : 0] != xt);
+                }
+                rsm[j] = __ballot(rstart[j]);
+            }
+            __syncthreads();                            // (the start words of the groups have been read by everyone: they now hold the runs')
+#pragma unroll
+            for (int j = 0; j < CH_ITEMS; j++)
+                if (lane == 0) startm[(u32)j * (CH_THREADS / 64) + wv] = rsm[j];
+            // the elements' positions through LDS (the keys are not needed any more)
+#pragma unroll
+            for (int j = 0; j < CH_ITEMS; j++) {
+                const u32 sl = (u32)j * CH_THREADS + tid;
+                if (sl < plen) key[sl] = myp[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < CH_ITEMS; j++) {
+                const u32 t = (u32)j * CH_THREADS + tid;
+                act[j] = t < plen;
+                dst[j] = t; newhead[j] = 0; alone[j] = false; moved[j] = false; ppos[j] = 0;
+                if (!act[j]) continue;
+                u32 w = (u32)j * (CH_THREADS / 64) + wv;
+                u64 m = rsm[j] & le;
+                while (m == 0ull) { w--; m = startm[w]; }              // (a group's first slot starts a run: the walk ends there at the latest)
+                const u32 rbeg = w * 64u + 63u - (u32)__clzll((long long)m);
+                const u32 less = rbeg - gst[j];
+                const u32 p = key[src[j]];
+                myp[j] = p;
+                newhead[j] = hd2[WIDE ? gst[j] : 0] + less;
+                alone[j] = rstart[j] && rend[j];
+                moved[j] = less != 0;
+                split_here |= less != 0 ? 1u : 0u;
+                if (!alone[j] && t - rbeg >= CH_CAP) s_wide = 1;        // a run of more than CH_CAP members stays: the chunk stays WIDE
+                if (CYCLIC && out && alone[j] && !prev.P) {
+                    if (FSL) {
+                        u32 f = fdir[p >> dsh];
+                        while (f + 1 < k32 && ftab[f + 1].x <= p) f++;
+                        const uint4 ft = ftab[f];
+                        ppos[j] = p != ft.x ? p - 1u : ft.x + ft.y - 1u;
+                    } else {
+                        const u64 f = factor_of(fstart, k, (u64)p);
+                        const u64 s0 = fstart[f], e1 = factor_end(fstart, k, n, f);
+                        ppos[j] = p == s0 ? (u32)(e1 - 1) : p - 1u;
+                    }
+                }
+            }
+            CH_MARK(1); CH_MARK(2);
+        } else {
+        // the group the tile's last start opens may go on in the next tile: it is left for that one
         if (!final_tile) {
             int w = CH_WORDS - 1;
             u64 m = startm[w];
@@ -203,9 +350,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
             for (int d = 1; d <= CH_WORDS_BACK; d++)
                 if (cout_l < 0 && lane + d < CH_WORDS) { const u64 nm = startm[lane + d]; if (nm) cout_l = (lane + d) * 64 + __ffsll((unsigned long long)nm) - 1; }
         }
-        const u64 le = lane == 63 ? ~0ull : (2ull << lane) - 1ull;       // slots of the word at or below mine
         u32 gs[CH_ITEMS], sz[CH_ITEMS];
-        bool act[CH_ITEMS];
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++) {
@@ -240,9 +385,6 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
         __syncthreads();
         CH_MARK(2);
         // order inside the group by counting (as dense_round_kernel)
-        u32 dst[CH_ITEMS], newhead[CH_ITEMS];
-        bool alone[CH_ITEMS], moved[CH_ITEMS];
-        u32 split_here = 0;
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++) {
             const u32 sl = (u32)j * CH_THREADS + tid;
@@ -286,6 +428,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
             alone[j] = eq == 1;
             moved[j] = less != 0;
             split_here |= eq < gsz ? 1u : 0u;
+        }
         }
         CH_MARK(3);
         u32 pv[CH_ITEMS];
@@ -340,6 +483,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_MIN_WAVES) void chunk_round_kernel(u
     if (tid0 == 0) {
         ccount[c] = wp;
         mvcount[c] = s_nmv;
+        if (WIDE && !s_wide) cwide[c] = 0;          // only groups of up to CH_CAP members are left: the other instantiation takes over
         if (s_split && __hip_atomic_load(&result[CHS_SPLIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
             __hip_atomic_store(&result[CHS_SPLIT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s_err) __hip_atomic_store(&result[CHS_ERR], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -373,24 +517,49 @@ __global__ __launch_bounds__(1024) void chunk_total_kernel(const u32 *__restrict
 }
 
 // chunks c0 .. c0 + nch over list slots [lo, hi): chunk i nominally starts at lo + i * S, actually at the first group start at
-// or after that (groups here have at most CH_CAP members, so the walk is short)
-__global__ __launch_bounds__(256) void chunk_init_kernel(const u32 *__restrict__ head, u64 lo, u64 hi, u32 S, u32 c0, u32 nch,
-                                                         u32 *__restrict__ cstart, u32 *__restrict__ ccount, u32 *__restrict__ mvcount)
+// or after that (groups here have at most CH_GROUP_MAX members; a wave looks at 64 slots at a time).  One wave per chunk; it also
+// walks the chunk once to see whether a group of more than CH_CAP members is in it (-> cwide).
+__device__ __forceinline__ u64 chunk_group_start_at_or_after(const u32 *__restrict__ head, u64 lo, u64 hi, u64 s, int lane)
 {
-    const u32 i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nch) return;
-    u64 s = lo + (u64)i * S;
     if (s > hi) s = hi;
-    while (s > lo && s < hi && head[s] == head[s - 1]) s++;
-    u64 e = hi;
-    if (i + 1 < nch) {
-        e = lo + (u64)(i + 1) * S;
-        if (e > hi) e = hi;
-        while (e > lo && e < hi && head[e] == head[e - 1]) e++;
+    if (s <= lo || s >= hi) return s;
+    for (;;) {
+        const u64 i = s + (u64)lane;
+        const bool st = i >= hi || head[i] != head[i - 1];
+        const u64 m = __ballot(st);
+        if (m) return s + (u64)(__ffsll((unsigned long long)m) - 1);
+        s += 64;
     }
-    cstart[c0 + i] = (u32)s;
-    ccount[c0 + i] = (u32)(e - s);
-    mvcount[c0 + i] = 0;
+}
+__global__ __launch_bounds__(256) void chunk_init_kernel(const u32 *__restrict__ head, u64 lo, u64 hi, u32 S, u32 c0, u32 nch,
+                                                         u32 *__restrict__ cstart, u32 *__restrict__ ccount, u32 *__restrict__ mvcount, u8 *__restrict__ cwide,
+                                                         bool may_be_wide)
+{
+    const u32 i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= nch) return;
+    const u64 s = chunk_group_start_at_or_after(head, lo, hi, lo + (u64)i * S, lane);
+    const u64 e = i + 1 < nch ? chunk_group_start_at_or_after(head, lo, hi, lo + (u64)(i + 1) * S, lane) : hi;
+    bool wide = false;
+    if (may_be_wide) {
+        u64 last = s;                           // the most recent group start seen
+        for (u64 b = s; b < e && !wide; b += 64) {
+            const u64 q = b + (u64)lane;
+            const bool st = q < e && (q == s || head[q] != head[q - 1]);
+            const u64 m = __ballot(st);
+            if (m) {
+                if (b + (u64)(__ffsll((unsigned long long)m) - 1) - last > CH_CAP) wide = true;
+                last = b + 63u - (u64)__clzll((long long)m);
+            }
+        }
+        if (e - last > CH_CAP) wide = true;
+    }
+    if (lane == 0) {
+        cstart[c0 + i] = (u32)s;
+        ccount[c0 + i] = (u32)(e - s);
+        mvcount[c0 + i] = 0;
+        cwide[c0 + i] = wide ? 1 : 0;
+    }
 }
 
 // what is left when no group splits any more (equal infinite words): the members take their group's slots in list order
@@ -588,34 +757,39 @@ struct BlRegroupOut {
             __hip_atomic_store(&result[CHS_SPLIT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
-// class of every element of the regrouped big list: 0 alone (finished), 1 in a group of 2 .. CH_CAP (leaves for a chunk), 2 stays
-__global__ __launch_bounds__(DG_THREADS) void bl_classify_kernel(const u32 *__restrict__ t_idx, const u32 *__restrict__ t_head, u64 m, u8 *__restrict__ cls)
-{
-    __shared__ u32 hd[DG_SPAN];
-    __shared__ u64 startm[DG_SPAN / 64];
-    const int tid = threadIdx.x;
-    const long long e0 = (long long)blockIdx.x * DG_OWN - DG_CAP;
-    DgSlots ds;
-    dg_detect(t_idx, t_head, m, e0, hd, startm, ds);
-#pragma unroll
-    for (int j = 0; j < DG_ITEMS; j++) {
-        if (!ds.kind[j]) continue;
-        const u64 e = (u64)(e0 + j * DG_THREADS + tid);
-        cls[e] = (u8)(ds.kind[j] == 2 ? 2 : (ds.sz[j] >= 2 ? 1 : 0));
+// class of every element of the (regrouped) big list: 0 alone (finished), 1 in a group of 2 .. CH_GROUP_MAX (leaves for a chunk),
+// 2 stays.  Group sizes from the run lengths of equal heads: an inclusive max-scan gives every element its run's first index, the
+// run's last element writes the length there.
+struct BlRunIn {
+    const u32 *head;
+    __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || head[i] != head[i - 1]) ? (u32)i + 1u : 0u; }
+};
+struct BlRunOut {
+    const u32 *head; u64 m; u32 *rstart; u32 *rsize;
+    __device__ __forceinline__ void operator()(u64 i, u32 v) const
+    {
+        const u32 s = v - 1u;
+        rstart[i] = s;
+        if (i + 1 == m || head[i + 1] != head[i]) rsize[s] = (u32)i - s + 1u;
     }
+};
+__device__ __forceinline__ u32 bl_class(const u32 *__restrict__ rstart, const u32 *__restrict__ rsize, u64 i)
+{
+    const u32 sz = rsize[rstart[i]];
+    return sz > CH_GROUP_MAX ? 2u : (sz >= 2 ? 1u : 0u);
 }
 struct BlSplitIn {
-    const u8 *cls;
-    __device__ __forceinline__ u64 operator()(u64 i) const { const u32 c = cls[i]; return (u64)(c == 1 ? 1u : 0u) | ((u64)(c == 2 ? 1u : 0u) << 32); }
+    const u32 *rstart; const u32 *rsize;
+    __device__ __forceinline__ u64 operator()(u64 i) const { const u32 c = bl_class(rstart, rsize, i); return (u64)(c == 1 ? 1u : 0u) | ((u64)(c == 2 ? 1u : 0u) << 32); }
 };
 struct BlSplitOut {
-    const u8 *cls; const u32 *t_idx; const u32 *t_head; u64 m;
+    const u32 *rstart; const u32 *rsize; const u32 *t_idx; const u32 *t_head; u64 m;
     u32 *x_idx, *x_head;          // where the leaving elements go (the chunk store's tail)
     u32 *s_idx, *s_head;          // the next big list
     unsigned long long *result;
     __device__ __forceinline__ void operator()(u64 i, u64 before) const
     {
-        const u32 c = cls[i];
+        const u32 c = bl_class(rstart, rsize, i);
         if (c == 1) { const u32 o = (u32)before; x_idx[o] = t_idx[i]; x_head[o] = t_head[i]; }
         else if (c == 2) { const u32 o = (u32)(before >> 32); s_idx[o] = t_idx[i]; s_head[o] = t_head[i]; }
         if (i + 1 == m) { result[CHS_EXIT] = (u64)(u32)before + (c == 1 ? 1u : 0u); result[CHS_STAY] = (before >> 32) + (c == 2 ? 1u : 0u); }
@@ -647,7 +821,8 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     const u64 maxchunks = a0 / S + 1024;                 // every append adds at most one ragged chunk; rounds are capped at 80
     const size_t ct4 = align_up((size_t)(maxchunks + 1) * 4, 256);
     char *base = nullptr, *ob = nullptr;
-    int rc = aux_reserve(ctx, 2 * e4 + e8 + 3 * ct4, &base);
+    const size_t ct1 = align_up((size_t)(maxchunks + 1), 256);
+    int rc = aux_reserve(ctx, 2 * e4 + e8 + 3 * ct4 + ct1, &base);
     if (rc == BWTS_E_NOMEM) return BWTS_OK;
     CH_TRY(rc);
     rc = aux_reserve_slot(ctx, 1, 2 * e8 + 2 * e4, &ob);
@@ -657,6 +832,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u32 *st_idx = (u32 *)base, *st_head = (u32 *)(base + e4);
     u64 *mv = (u64 *)(base + 2 * e4);
     u32 *cstart = (u32 *)(base + 2 * e4 + e8), *ccount = (u32 *)(base + 2 * e4 + e8 + ct4), *mvcount = (u32 *)(base + 2 * e4 + e8 + 2 * ct4);
+    u8 *cwide = (u8 *)(base + 2 * e4 + e8 + 3 * ct4);
     u64 *slots = ctx->d_small + SM_CHSLOT;
     const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
     PrevSym prev{sp.carry_src, d_T, n, d_fstart, k};
@@ -714,22 +890,20 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                              (unsigned long long)a_small, S, (unsigned long long)m_big);
 
     // ---- big list buffers (the order sort's block, free again) ----
-    const size_t m4 = align_up((size_t)m_big * 4, 256), m8 = align_up((size_t)m_big * 8, 256), m1 = align_up((size_t)m_big, 256);
+    const size_t m4 = align_up((size_t)m_big * 4, 256), m8 = align_up((size_t)m_big * 8, 256);
     const bool step4_ok = [ctx] { const char *e = bwts_knob(ctx, "BWTS_DENSE_STEP"); return !(e && atoi(e) == 2); }();
     const int nk = step4_ok ? 3 : 1;
     u32 *bl_idx[2] = {nullptr, nullptr}, *bl_head[2] = {nullptr, nullptr}, *t_idx = nullptr, *t_head = nullptr, *bv[2] = {nullptr, nullptr}, *sv1 = nullptr;
     u64 *bk[2] = {nullptr, nullptr}, *k23 = nullptr, *sk1 = nullptr;
-    u8 *cls = nullptr;
     int blc = 0;
     if (m_big) {
         char *bb = nullptr;
-        CH_TRY(aux_reserve_slot(ctx, 1, 4 * m8 + 9 * m4 + m1, &bb));
+        CH_TRY(aux_reserve_slot(ctx, 1, 4 * m8 + 9 * m4, &bb));
         char *q = bb;
         for (int i = 0; i < 2; i++) { bl_idx[i] = (u32 *)q; q += m4; bl_head[i] = (u32 *)q; q += m4; }
         t_idx = (u32 *)q; q += m4; t_head = (u32 *)q; q += m4;
         bv[0] = (u32 *)q; q += m4; bv[1] = (u32 *)q; q += m4; sv1 = (u32 *)q; q += m4;
         bk[0] = (u64 *)q; q += m8; bk[1] = (u64 *)q; q += m8; k23 = (u64 *)q; q += m8; sk1 = (u64 *)q; q += m8;
-        cls = (u8 *)q;
         CH_HIP(hipMemcpyAsync(bl_idx[0], st_idx + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
         CH_HIP(hipMemcpyAsync(bl_head[0], st_head + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
     }
@@ -738,13 +912,46 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u64 tail = a_small;                     // the store behind it is free: chunks leaving the big list are appended there
     if (a_small) {
         nchunks = (u32)((a_small + S - 1) / S);
-        chunk_init_kernel<<<dim3((nchunks + 255) / 256), dim3(256), 0, ctx->stream>>>(st_head, 0, a_small, S, 0, nchunks, cstart, ccount, mvcount);
+        chunk_init_kernel<<<dim3((nchunks + 3) / 4), dim3(256), 0, ctx->stream>>>(st_head, 0, a_small, S, 0, nchunks, cstart, ccount, mvcount, cwide, false);
         CH_HIP(hipGetLastError());
+    }
+
+    u64 a_chunks = a_small;                 // elements in chunks after the last evaluated round
+    bool wide_possible = false;             // some chunk may be flagged WIDE: the second instantiation is launched as well
+    if (m_big) {
+        // the one-off order left every group of more than CH_CAP members in the big list; those of up to CH_GROUP_MAX go to chunks right
+        // away (unordered, like everything that leaves the big list later): their chunks are flagged WIDE and take the sorting instantiation of the round kernel
+        CH_HIP(hipMemsetAsync(slots, 0, CH_SLOT_WORDS * sizeof(u64), ctx->stream));
+        {
+            SpanGuard g(ctx, BWTS_K_RERANK, m_big, 28 * m_big);
+            BlRunIn nin{bl_head[0]};
+            BlRunOut nout{bl_head[0], m_big, bv[0], bv[1]};
+            CH_TRY((device_scan<true, u32>(ctx, m_big, nin, nout, OpMax(), 0u, sp.scan_temp)));
+            BlSplitIn sin{bv[0], bv[1]};
+            BlSplitOut sout{bv[0], bv[1], bl_idx[0], bl_head[0], m_big, st_idx + tail, st_head + tail, bl_idx[1], bl_head[1], (unsigned long long *)slots};
+            CH_TRY((device_scan<false, u64>(ctx, m_big, sin, sout, OpAdd(), (u64)0, sp.scan_temp)));
+        }
+        CH_TRY(read_small(ctx, SM_CHSLOT, CH_SLOT_WORDS));
+        const u64 m_exit = ctx->h_small[SM_CHSLOT + CHS_EXIT], m_stay = ctx->h_small[SM_CHSLOT + CHS_STAY];
+        if (m_exit + m_stay != m_big || tail + m_exit > a0) CH_FAIL("first split of the big list");
+        if (m_exit) {
+            const u32 add = (u32)((m_exit + S - 1) / S);
+            if ((u64)nchunks + add > maxchunks) CH_FAIL("chunk table full");
+            chunk_init_kernel<<<dim3((add + 3) / 4), dim3(256), 0, ctx->stream>>>(st_head, tail, tail + m_exit, S, nchunks, add, cstart, ccount, mvcount, cwide, true);
+            CH_HIP(hipGetLastError());
+            nchunks += add;
+            tail += m_exit;
+            a_chunks += m_exit;
+            wide_possible = true;
+        }
+        blc = 1;
+        m_big = m_stay;
+        if (round_trace) fprintf(stderr, "[chunks] groups of up to %d members leave the big list at once: %llu elements, %llu stay\n", (int)CH_GROUP_MAX,
+                                 (unsigned long long)m_exit, (unsigned long long)m_stay);
     }
 
     u64 h = (u64)al.hstep;
     const int hshift = nk == 3 ? 2 : 1;
-    u64 a_chunks = a_small;                 // elements in chunks after the last evaluated round
     bool finished = false, stable = false;
     while (!finished) {
 #ifdef CH_PROFILE
@@ -759,11 +966,16 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             hs[b] = h;
             if (nchunks) {
                 SpanGuard g(ctx, BWTS_K_ROUND, 0, 0);          // (elements and bytes are added below, once the round's true size is known)
-#define CH_LAUNCH(NK, FS) chunk_round_kernel<CYCLIC, NK, FS><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, sp.rank, n, h, \
-                                                                                                        d_fstart, k, prev, out, res)
+#define CH_LAUNCH(NK, FS, WD) chunk_round_kernel<CYCLIC, NK, FS, WD><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, cwide, mv, mvcount, \
+                                                                                                        sp.rank, n, h, d_fstart, k, prev, out, res)
                 const bool fsl = CYCLIC && k <= CH_FS;
-                if (nk == 3) { if (fsl) CH_LAUNCH(3, CYCLIC); else CH_LAUNCH(3, false); }
-                else { if (fsl) CH_LAUNCH(1, CYCLIC); else CH_LAUNCH(1, false); }
+                if (nk == 3) { if (fsl) CH_LAUNCH(3, CYCLIC, false); else CH_LAUNCH(3, false, false); }
+                else { if (fsl) CH_LAUNCH(1, CYCLIC, false); else CH_LAUNCH(1, false, false); }
+                if (wide_possible) {
+                    // (behind the other one: a chunk whose last large group has just split is taken over in the NEXT round)
+                    if (nk == 3) { if (fsl) CH_LAUNCH(3, CYCLIC, true); else CH_LAUNCH(3, false, true); }
+                    else { if (fsl) CH_LAUNCH(1, CYCLIC, true); else CH_LAUNCH(1, false, true); }
+                }
 #undef CH_LAUNCH
                 CH_HIP(hipGetLastError());
             }
@@ -782,7 +994,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 CH_HIP(hipGetLastError());
             }
             if (m_big) {
-                const int big_bits = bitlen_u64(m_big / (CH_CAP + 1)) + rb;          // ordinals < m_big / (CH_CAP + 1)
+                const int big_bits = bitlen_u64(m_big / (CH_GROUP_MAX + 1)) + rb;          // ordinals < m_big / (CH_GROUP_MAX + 1)
                 if (big_bits > 64) return BWTS_E_RANGE;
                 SortPlan bp;
                 bp.tile_hist = sp.tile_hist; bp.scan_temp = sp.scan_temp;
@@ -816,10 +1028,12 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 DgRegroupIn rin{sorted_k1, m_big, rb, src, nk == 3 ? k23 : nullptr};
                 BlRegroupOut rout{sorted_k1, positions, bl_head[blc], m_big, rb, t_idx, t_head, sp.rank, prev, out, res, src, nk == 3 ? k23 : nullptr};
                 CH_TRY((device_scan<true, u64>(ctx, m_big, rin, rout, OpMax2(), (u64)0, sp.scan_temp)));
-                bl_classify_kernel<<<dim3((unsigned)((m_big + DG_OWN - 1) / DG_OWN)), dim3(DG_THREADS), 0, ctx->stream>>>(t_idx, t_head, m_big, cls);
-                CH_HIP(hipGetLastError());
-                BlSplitIn sin{cls};
-                BlSplitOut sout{cls, t_idx, t_head, m_big, st_idx + tail, st_head + tail, bl_idx[blc ^ 1], bl_head[blc ^ 1], res};
+                // (the sort buffers are free again: run starts and lengths go there)
+                BlRunIn nin{t_head};
+                BlRunOut nout{t_head, m_big, bv[0], bv[1]};
+                CH_TRY((device_scan<true, u32>(ctx, m_big, nin, nout, OpMax(), 0u, sp.scan_temp)));
+                BlSplitIn sin{bv[0], bv[1]};
+                BlSplitOut sout{bv[0], bv[1], t_idx, t_head, m_big, st_idx + tail, st_head + tail, bl_idx[blc ^ 1], bl_head[blc ^ 1], res};
                 CH_TRY((device_scan<false, u64>(ctx, m_big, sin, sout, OpAdd(), (u64)0, sp.scan_temp)));
             }
             h = h > (1ull << 60) ? h : h << hshift;
@@ -835,7 +1049,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 if (round_trace) fprintf(stderr, "[chunks] chunk %llu of %u: group [%d, %d) plen %llu len %llu rp %llu slot %llu\n", (unsigned long long)r[5] - 1, nchunks,
                                          (int)(r[6] >> 32), (int)(u32)r[6], (unsigned long long)(r[7] >> 48), (unsigned long long)((r[7] >> 32) & 0xffff),
                                          (unsigned long long)((r[7] >> 16) & 0xffff), (unsigned long long)(r[7] & 0xffff));
-                CH_FAIL("a chunk met a group larger than CH_CAP");
+                CH_FAIL("a chunk met a group larger than it may hold");
             }
             const u64 in_chunks = nchunks ? r[CHS_TOTAL] : 0;
             u64 m_exit = 0, m_stay = 0;
@@ -861,7 +1075,8 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             if (m_exit) {
                 const u32 add = (u32)((m_exit + S - 1) / S);
                 if ((u64)nchunks + add > maxchunks) CH_FAIL("chunk table full");
-                chunk_init_kernel<<<dim3((add + 255) / 256), dim3(256), 0, ctx->stream>>>(st_head, tail, tail + m_exit, S, nchunks, add, cstart, ccount, mvcount);
+                chunk_init_kernel<<<dim3((add + 3) / 4), dim3(256), 0, ctx->stream>>>(st_head, tail, tail + m_exit, S, nchunks, add, cstart, ccount, mvcount, cwide, true);
+                wide_possible = true;
                 CH_HIP(hipGetLastError());
                 nchunks += add;
                 tail += m_exit;
