@@ -253,6 +253,25 @@ def test_chunk_rounds_many_factors_equal_rotations(ctx):
     assert np.array_equal(ctx.inverse(y), x)
 
 
+def test_chunk_rounds_groups_of_hundreds_and_thousands(ctx):
+    """Phrases pasted 300 ... 6000 times into noise: after round 0 the tied list has groups of a few hundred members (WIDE chunks: a
+    tile ordered by the workgroup's bitonic sort), of up to 2048 (a tile of their own) and of several thousand (the big list, whose
+    pieces leave for chunks as they shrink) next to pairs and triples; several sizes of the whole, two alphabets."""
+    for seed, n, sigma in ((77, 1 << 21, 96), (78, (1 << 20) + 12345, 4), (79, 3 << 20, 200)):
+        rng = np.random.default_rng(seed)
+        x = rng.integers(0, sigma, size=n, dtype=np.uint8)
+        for times in (300, 700, 1500, 2048, 2049, 3000, 6000):
+            L = int(rng.integers(24, 90))
+            ph = rng.integers(0, sigma, size=L, dtype=np.uint8)
+            for at in rng.integers(0, n - L, size=times):
+                x[at:at + L] = ph
+        y = ctx.forward(x)
+        t = ctx.timings()
+        assert t.active_after_round0 >= 1 << 16                   # (the chunk form takes lists from 65 536 elements on)
+        assert np.array_equal(y, O.forward(x)), (seed, n, sigma)
+        assert np.array_equal(ctx.inverse(y), x)
+
+
 def test_dense_ties_large_vs_oracle(ctx):
     """n >= 2^22 with most elements tied after round 0: the dense rank array is built by the binned scatter."""
     block = O.generate("zipf", 1 << 21, 5)
@@ -917,7 +936,7 @@ def test_text_1GiB_golden_and_properties(ctx):
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_alternate_paths(env):
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
-           "-k", "(small or mid_size or deep_repeats or dense_ties or dense_rounds or text_16MiB or reference_unbwts_vectors_through_cabi) and not alternate"]
+           "-k", "(small or mid_size or deep_repeats or dense_ties or dense_rounds or chunk_rounds or text_16MiB or reference_unbwts_vectors_through_cabi) and not alternate"]
     # (-k matches case-insensitively and looks at parameter ids too: without the exclusion, an id like BWTS_RX_SMALL=0
     # makes the child select this very test and start a child of its own.)
     if os.environ.get("BWTS_TEST_CHILD"):
