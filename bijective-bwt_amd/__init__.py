@@ -33,7 +33,7 @@ H_COUNT = len(H_NAMES)
 
 # every symbol include/bwts.h declares (the drop-in surface) ...
 EXPORTS = [
-    "bwts_ctx_create", "bwts_ctx_destroy", "bwts_forward", "bwts_inverse", "bwts_forward_sink", "bwts_inverse_sink",
+    "bwts_ctx_create", "bwts_ctx_destroy", "bwts_ctx_release_memory", "bwts_forward", "bwts_inverse", "bwts_forward_sink", "bwts_inverse_sink",
     "bwts_forward_device", "bwts_inverse_device", "bwts_last_timings", "bwts_kernel_class_name", "bwts_strerror",
     "bwts_last_hip_error", "bwts_set_timing", "bwts_host_alloc", "bwts_host_free", "bwts_host_cost_name",
     "bwts_forward_batch", "bwts_inverse_batch",
@@ -95,6 +95,8 @@ def lib():
         L.bwts_ctx_create.argtypes = [ctypes.POINTER(vp), i32]
         L.bwts_ctx_destroy.argtypes = [vp]
         L.bwts_ctx_destroy.restype = None
+        L.bwts_ctx_release_memory.argtypes = [vp]
+        L.bwts_ctx_release_memory.restype = ctypes.c_int
         for name in ("bwts_forward", "bwts_inverse", "bwts_forward_device", "bwts_inverse_device"):
             getattr(L, name).argtypes = [vp, vp, u64, vp]
         L.bwts_last_timings.argtypes = [vp, ctypes.POINTER(Timings)]
@@ -183,6 +185,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def release_memory(self):
+        """Hands the device memory the context keeps between calls back to the device (bwts_ctx_release_memory)."""
+        self._check(lib().bwts_ctx_release_memory(self._h))
 
     def _check(self, rc):
         if rc != 0:

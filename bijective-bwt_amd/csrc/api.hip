@@ -234,6 +234,23 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
     delete ctx;
 }
 
+// A context keeps what its last calls allocated on the device (a 12 GiB input leaves ~100-200 GiB there) so that the next call starts at
+// once; a caller who wants the memory back without giving up the context asks for it here.  Pinned staging and the small blocks stay.
+extern "C" int bwts_ctx_release_memory(bwts_ctx *ctx)
+{
+    if (!ctx) return BWTS_E_ARG;
+    HIPC(hipSetDevice(ctx->device));
+    HIPC(hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) { HIPC(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; ctx->arena_off = 0; }
+    for (int i = 0; i < BWTS_AUX_SLOTS; i++)
+        if (ctx->aux[i]) { HIPC(hipFree(ctx->aux[i])); ctx->aux[i] = nullptr; ctx->aux_cap[i] = 0; }
+    for (char *b : ctx->tied_blk) HIPC(hipFree(b));
+    ctx->tied_blk.clear();
+    for (int i = 0; i < 4; i++)
+        if (ctx->d_io[i]) { HIPC(hipFree(ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
+    return BWTS_OK;
+}
+
 // ------------------------------------------------------------------------------------
 // transforms
 // ------------------------------------------------------------------------------------

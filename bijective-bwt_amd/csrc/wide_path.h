@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void wide_bucket_finish_kernel(const u64 *__re
         // (a position rebuilt from sorted data: should key build and prefix histogram ever disagree again, this is an error code,
         // not a write through a stale position -- the GPU fault of round 2's fuzz run)
         if (p >= n) { *overflow = 2; continue; }
-        rank64[p] = r;
+        if (rank64) rank64[p] = r;
         out[base + i] = CARRY ? S[i] : prev(p);
         if ((km >> lane) & 1ull) {
             const u64 t = tbase + (u64)(u32)pr + (u64)__popcll(km & lanemask_lt());
@@ -257,6 +257,75 @@ struct WideRestOut {
     __device__ __forceinline__ void operator()(u64 i, u32 v) const { out[tl.head(lo + i) + ((u64)i - (u64)(v - 1u))] = prev(tl.pos(lo + i)); }
 };
 
+// ---- few ties: the groups are ordered by comparing their members' rotations in the text itself ------------------------------
+// i.i.d.-like inputs leave a few thousand positions tied after the first sort, in pairs and triples that differ a few symbols on.
+// For them the n-entry rank array -- 8 n bytes, one random 8-byte write per position -- is only ever read at a few thousand
+// places, so the forward first runs WITHOUT it: the buckets are finished without rank writes, and every tied group is put in
+// order by one thread comparing the members' cyclic rotations (each inside its own Lyndon factor: mk_bwts_sa.c:74-112 orders
+// positions by their factor's rotation, read round and round) from the first symbol the keys did not cover.  Anything that does
+// not fit this form -- more than WIDE_DIRECT_MAX tied positions, a group of more than WIDE_DIRECT_GROUP members, two rotations
+// that agree beyond WIDE_DIRECT_DEPTH symbols (long repeats, equal long factors) -- makes the caller run again with the rank array.
+#define WIDE_DIRECT_MAX   (1ull << 22)
+#define WIDE_DIRECT_GROUP 32
+#define WIDE_DIRECT_DEPTH 4096ull
+struct WideGroupIn {
+    TiedList tl;
+    __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || tl.head(i) != tl.head(i - 1)) ? 1u : 0u; }
+};
+struct WideGroupOut {
+    TiedList tl; u32 *gstart; u64 a; u64 *groups;
+    __device__ __forceinline__ void operator()(u64 i, u32 before) const
+    {
+        const bool st = i == 0 || tl.head(i) != tl.head(i - 1);
+        if (st) gstart[before] = (u32)i;
+        if (i + 1 == a) *groups = (u64)before + (st ? 1u : 0u);
+    }
+};
+__global__ __launch_bounds__(64) void wide_direct_groups_kernel(TiedList tl, const u32 *__restrict__ gstart, u64 ngroups, u64 a, const u8 *__restrict__ T, u64 n,
+                                                                const u64 *__restrict__ fstart, u64 k, u64 skip, PrevSym64 prev, u8 *__restrict__ out,
+                                                                u64 *__restrict__ unresolved)
+{
+    const u64 g = (u64)blockIdx.x * 64 + threadIdx.x;
+    if (g >= ngroups) return;
+    const u64 s = gstart[g], e = g + 1 < ngroups ? (u64)gstart[g + 1] : a;
+    const u32 cnt = (u32)(e - s);
+    if (cnt > WIDE_DIRECT_GROUP) { *unresolved = 1; return; }
+    u64 pos[WIDE_DIRECT_GROUP], fs[WIDE_DIRECT_GROUP], fl[WIDE_DIRECT_GROUP];
+    for (u32 i = 0; i < cnt; i++) {
+        const u64 p = tl.pos(s + i);
+        const u64 f = factor_of64(fstart, k, p);
+        pos[i] = p; fs[i] = fstart[f]; fl[i] = (f + 1 < k ? fstart[f + 1] : n) - fs[i];
+    }
+    // insertion sort; less(x, y): the rotations at pos[x], pos[y], from symbol `skip` on
+    bool bad = false;
+    for (u32 i = 1; i < cnt && !bad; i++) {
+        const u64 p = pos[i], ps = fs[i], pl = fl[i];
+        u32 j = i;
+        while (j > 0) {
+            const u64 q = pos[j - 1], qs = fs[j - 1], ql = fl[j - 1];
+            u64 op = (p - ps + skip) % pl, oq = (q - qs + skip) % ql;
+            bool p_less = false, decided = false;
+            // two periodic words that agree on (sum of their periods) symbols are equal for ever (Fine and Wilf): such members are
+            // identical rotations of identical factors, emit the same byte, and may stay in either order
+            const u64 lim = pl + ql < WIDE_DIRECT_DEPTH ? pl + ql : WIDE_DIRECT_DEPTH;
+            for (u64 d = 0; d < lim; d++) {
+                const u8 cp = T[ps + op], cq = T[qs + oq];
+                if (cp != cq) { p_less = cp < cq; decided = true; break; }
+                if (++op == pl) op = 0;
+                if (++oq == ql) oq = 0;
+            }
+            if (!decided && pl + ql > WIDE_DIRECT_DEPTH) { bad = true; break; }
+            if (!p_less) break;
+            pos[j] = q; fs[j] = qs; fl[j] = ql;
+            j--;
+        }
+        pos[j] = p; fs[j] = ps; fl[j] = pl;
+    }
+    if (bad) { *unresolved = 1; return; }
+    const u64 h0 = tl.head(s);
+    for (u32 i = 0; i < cnt; i++) out[h0 + i] = prev(pos[i]);
+}
+
 // room for `elements` list entries; the block table goes to the device whenever it has changed (or `push` asks)
 static int wide_tied_ensure(bwts_ctx *ctx, u64 elements, int lg, u64 **d_tab, bool push)
 {
@@ -283,10 +352,11 @@ static int wide_tied_ensure(bwts_ctx *ctx, u64 elements, int lg, u64 **d_tab, bo
     return BWTS_OK;
 }
 
-struct WideKnobs { int seg_log2; u64 bucket_cap; u64 part; int tblock_log2; };
+struct WideKnobs { int seg_log2; u64 bucket_cap; u64 part; int tblock_log2; int direct; };
 static WideKnobs wide_knobs(const bwts_ctx *ctx)
 {
-    WideKnobs kn{30, 1ull << 30, 0, 0};
+    WideKnobs kn{30, 1ull << 30, 0, 0, -1};
+    if (const char *e = bwts_knob(ctx, "BWTS_WIDE_DIRECT")) kn.direct = atoi(e) ? 1 : 0;     // 1: ties by direct comparison only, 0: rank array at once
     if (const char *e = bwts_knob(ctx, "BWTS_WIDE_PART")) { const long long v = atoll(e); if (v >= 64) kn.part = (u64)v; }             // elements per part of a round
     if (const char *e = bwts_knob(ctx, "BWTS_WIDE_TBLOCK_LOG2")) { const int v = atoi(e); if (v >= 6 && v <= 30) kn.tblock_log2 = v; } // tied-list block size
     if (const char *e = bwts_knob(ctx, "BWTS_WIDE_SEG_LOG2")) { const int v = atoi(e); if (v >= 11 && v <= 31) kn.seg_log2 = v; }      // >= log2(KB_TILE)
@@ -294,15 +364,17 @@ static WideKnobs wide_knobs(const bwts_ctx *ctx)
     return kn;
 }
 
-static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
+// direct: without the rank array (see wide_direct_groups_kernel); *again is set when the input turns out to need it
+static int forward_wide_run(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out, bool direct, bool *again)
 {
+    *again = false;
     if (n > (1ull << 36)) return BWTS_E_RANGE;
     WideKnobs kn = wide_knobs(ctx);
     // larger buckets (fewer collection passes over the text) while rank array + bucket buffers + in/out leave room: 12 GiB of DNA
     // take 2.03 s with buckets of 2^30 elements (before the carried byte), 1.86 s with 2^31, 1.62 s with 3 * 2^30 (203 GiB on the device)
     if (!bwts_knob(ctx, "BWTS_WIDE_BUCKET")) {
-        if (n <= (13ull << 30)) kn.bucket_cap = 3ull << 30;
-        else if (n <= (14ull << 30)) kn.bucket_cap = 1ull << 31;
+        if (n <= (13ull << 30) || (direct && n <= (48ull << 30))) kn.bucket_cap = 3ull << 30;
+        else if (n <= (14ull << 30) || direct) kn.bucket_cap = 1ull << 31;
     }
     const u64 seg = 1ull << kn.seg_log2;
     const u64 nseg = (n + seg - 1) / seg;
@@ -316,12 +388,12 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     u64 sort_max = Mb > seg ? Mb : seg;                            // largest sort or scan through tile_hist / scan_temp:
     if (sort_max < LYN_CAND_CAP) sort_max = LYN_CAND_CAP;          // a bucket, a segment, or the factor candidates
     // ---- arena layout -------------------------------------------------------------------------------------------------
-    const size_t need = align_up(n * 8, 256) + align_up(seg * 8, 256) + align_up(seg, 256) + align_up((tiles + 1) * 8, 256) + scan_temp_bytes(n) +
+    const size_t need = (direct ? 0 : align_up(n * 8, 256)) + align_up(seg * 8, 256) + align_up(seg, 256) + align_up((tiles + 1) * 8, 256) + scan_temp_bytes(n) +
                         2 * align_up(Mb * 8, 256) + 2 * align_up(Mb * 4, 256) + 4 * align_up(Mb, 256) + radix_tile_hist_bytes(sort_max) +
                         scan_temp_bytes(sort_max) + 3 * align_up(mwords * 8, 256) + 8 * align_up(LYN_CAND_CAP * 8, 256) +
                         align_up(nseg * WIDE_PREFIXES * 4, 256) + align_up((WIDE_MAX_PARTS + 2) * 8, 256) + (1 << 16);
     BWTS_TRY(arena_reserve(ctx, need));
-    u64 *rank64 = arena_array<u64>(ctx, n);
+    u64 *rank64 = direct ? nullptr : arena_array<u64>(ctx, n);
     u64 *segkeys = arena_array<u64>(ctx, seg);
     u8 *segprev = arena_array<u8>(ctx, seg);
     u64 *tile_min = arena_array<u64>(ctx, tiles + 1);
@@ -339,7 +411,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     u64 *d_cuts = arena_array<u64>(ctx, WIDE_MAX_PARTS + 2);
     u64 **d_tab = (u64 **)arena_array<u64>(ctx, WIDE_TB_MAX);
     if (!d_cuts || !d_tab) return BWTS_E_NOMEM;
-    if (!rank64 || !segkeys || !segprev || !tile_min || !pre_temp || !bk[1] || !bv[1] || !bs_src || !bs_buf[1] || !bs_fin || !tile_hist || !scan_temp ||
+    if ((!direct && !rank64) || !segkeys || !segprev || !tile_min || !pre_temp || !bk[1] || !bv[1] || !bs_src || !bs_buf[1] || !bs_fin || !tile_hist || !scan_temp ||
         !headw || !keepw || !prew || !cand[1] || !cvals[1] || !fstart || !d_hist)
         return BWTS_E_NOMEM;
 
@@ -538,6 +610,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
         const u64 tied_before = tied_total;
         tied_total = ctx->h_small[SM_COUNTERS + 24];
         if (tied_total < tied_before || tied_total - tied_before > m) return BWTS_E_INTERNAL;
+        if (direct && tied_total > WIDE_DIRECT_MAX) { *again = true; return BWTS_OK; }          // many ties: this input needs the ranks
         BWTS_TRY(wide_tied_ensure(ctx, tied_total ? tied_total : 1, tlg, d_tab, false));
         {
             SpanGuard g(ctx, BWTS_K_EMIT, m, 15 * m);
@@ -559,6 +632,29 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     if (ctx->h_small[SM_COUNTERS + 25] || a != tied_total) return BWTS_E_INTERNAL; // (the list had room for every count read above)
     ctx->tm.active_after_round0 = a;
     ctx->tm.round_active[0] = a;
+    if (direct) {
+        if (a) {
+            if (a > WIDE_DIRECT_MAX) { *again = true; return BWTS_OK; }
+            SpanGuard g(ctx, BWTS_K_RERANK, a, 40 * a);
+            u32 *gstart = bv[0];                         // (a <= WIDE_DIRECT_MAX <= the buffers' size)
+            if (a > Mb) return BWTS_E_INTERNAL;
+            HIPC(hipMemsetAsync(cnt, 0, 4 * sizeof(u64), ctx->stream));
+            WideGroupIn gin{tl};
+            WideGroupOut gout{tl, gstart, a, cnt + 3};
+            BWTS_TRY((device_scan<false, u32>(ctx, a, gin, gout, OpAdd(), 0u, scan_temp)));
+            BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
+            const u64 ngroups = ctx->h_small[SM_COUNTERS + 3];
+            if (ngroups == 0 || ngroups > a) return BWTS_E_INTERNAL;
+            wide_direct_groups_kernel<<<dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0, ctx->stream>>>(tl, gstart, ngroups, a, d_T, n, fstart, k, (u64)al.hstep, prev,
+                                                                                                          d_out, cnt + 1);
+            HIPC(hipGetLastError());
+            BWTS_TRY(read_small(ctx, SM_COUNTERS, 4));
+            if (ctx->h_small[SM_COUNTERS + 1]) { *again = true; return BWTS_OK; }               // a large group, or rotations equal for thousands of symbols
+        }
+        ctx->tm.rounds = a ? 2 : 1;
+        if (a && 1 < BWTS_MAX_ROUND_STATS) ctx->tm.round_active[1] = 0;
+        return BWTS_OK;
+    }
 
     // ---- rounds over the tied list, part by part ----------------------------------------------------------------------------
     u32 rounds = 1;
@@ -645,4 +741,18 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     }
     ctx->tm.rounds = rounds;
     return BWTS_OK;
+}
+
+static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
+{
+    const WideKnobs kn = wide_knobs(ctx);
+    bool again = false;
+    if (kn.direct != 0) {
+        // first without the rank array: an input with few ties never needs it (8 n bytes, n random writes); one with many says so
+        // after its first bucket
+        const int rc = forward_wide_run(ctx, d_T, n, d_out, true, &again);
+        if (rc != BWTS_OK || !again) return rc;
+        if (kn.direct == 1) return BWTS_E_RANGE;          // (forced: the tests want to know that this form did it)
+    }
+    return forward_wide_run(ctx, d_T, n, d_out, false, &again);
 }

@@ -102,6 +102,10 @@ typedef struct bwts_timings {
 
 int  bwts_ctx_create(bwts_ctx **out, int device_id);
 void bwts_ctx_destroy(bwts_ctx *ctx);
+/* A context keeps the device memory its calls needed (arena, side blocks, in/out buffers of the host-buffer entry points) for the next
+ * call; this hands it back to the device without ending the context.  The next call allocates again.  (No reference counterpart:
+ * mk_bwts_sa.c / unbwts.c are one-shot programs that exit.) */
+int bwts_ctx_release_memory(bwts_ctx *ctx);
 
 /* Host-buffer entry points: in/out are caller-owned host memory (may be an
  * mmap of a file, unpinned); staged through pinned buffers with hipMemcpyAsync. */

@@ -691,6 +691,7 @@ for kind, n, seed, part, lg in (("text", 300007, 11, 3000, 12), ("text", (1 << 2
                                 ("zipf", 400009, 14, 1000, 10)):
     os.environ["BWTS_WIDE_BUCKET"] = str(max(256, n // 5))
     os.environ["BWTS_WIDE_PART"] = str(part); os.environ["BWTS_WIDE_TBLOCK_LOG2"] = str(lg)
+    os.environ["BWTS_WIDE_DIRECT"] = "0"               # (the rank array and the rounds at once, also where the ties are few)
     x = O.generate(kind, n, seed)
     with pkg.Context(0) as ctx:
         y = ctx.forward(x)
@@ -699,6 +700,25 @@ for kind, n, seed, part, lg in (("text", 300007, 11, 3000, 12), ("text", (1 << 2
         print("parts:", kind, n, "rounds", t.rounds, "tied", t.active_after_round0, "parts of", part, "blocks of", 1 << lg)
         if kind == "text": assert t.active_after_round0 > 8 * part
 del os.environ["BWTS_WIDE_PART"], os.environ["BWTS_WIDE_TBLOCK_LOG2"]
+# few ties: no rank array at all, the tied groups ordered by comparing rotations in the text (forced: a fallback would be an error);
+# text needs the ranks and says so
+os.environ["BWTS_WIDE_DIRECT"] = "1"
+for kind, n, seed in (("zipf", 250001, 21), ("dna", 400003, 22), ("uniform256", 100000, 23), ("dna", (1 << 21) + 11, 24)):
+    os.environ["BWTS_WIDE_BUCKET"] = str(max(256, n // 7))
+    x = O.generate(kind, n, seed)
+    with pkg.Context(0) as ctx:
+        y = ctx.forward(x)
+        t = ctx.timings()
+        assert np.array_equal(y, O.forward(x)), ("direct", kind, n)
+        print("direct:", kind, n, "tied", t.active_after_round0, "factors", t.factors)
+x = O.generate("text", 200003, 25)
+with pkg.Context(0) as ctx:
+    try:
+        ctx.forward(x)
+        raise AssertionError("text went through without the rank array")
+    except pkg.BwtsError as e:
+        assert e.code == -5, e
+del os.environ["BWTS_WIDE_DIRECT"]
 for kat in (b"banana", b"mississippi", b"abracadabra", b"the quick brown fox jumps over the lazy dog"):
     os.environ["BWTS_WIDE_BUCKET"] = "256"
     with pkg.Context(0) as ctx:
@@ -806,6 +826,42 @@ def test_wide_12GiB_dna_round_trip(ctx, pkg):
     assert _lf_walk_matches_text(x, y, 200000) == 200000
     assert t.factors >= 1 and t.rounds >= 1 and ti.factors == t.factors     # LF cycles = Lyndon factors
     print("12 GiB: forward %.0f ms, inverse %.0f ms, factors %d" % (t.total_ms, ti.total_ms, t.factors))
+
+
+def test_wide_6GiB_text_round_trip(ctx, pkg):
+    """text(6 GiB): beyond 2^32 positions with 71 % of them tied after the first sort (4.6 * 10^9): the tied list in blocks taken as it
+    grows, the rounds over it part by part (three parts per round at first), 64-bit ranks.  The forward first tries without the rank
+    array and is told after its first bucket that this input needs it.  Round trip exact on the device, the bytes a permutation of
+    the input's, bwts[0] = T[n-1]."""
+    n = 6 << 30
+    ctx.release_memory()                     # (what earlier tests left with the context: this case takes 215 GiB of its own)
+    try:
+        d_in, d_out, d_back = ctx.alloc(n), ctx.alloc(n), ctx.alloc(n)
+    except pkg.BwtsError:
+        pytest.skip("not enough device memory")
+    try:
+        ctx.generate("text", 1, n, d_in)
+        try:
+            ctx.forward_device(d_in, n, d_out)
+        except pkg.BwtsError as e:
+            if e.code == -3:
+                pytest.skip("not enough free device memory for the 6 GiB text case")
+            raise
+        t = ctx.timings()
+        assert t.active_after_round0 > n // 2 and t.rounds >= 10
+        ctx.inverse_device(d_out, n, d_back)
+        assert ctx.device_equal(d_in, d_back, n)                 # unbwts o mk_bwts = id
+        x, y = d_in.download(), d_out.download()
+    finally:
+        for b in (d_in, d_out, d_back):
+            b.free()
+    assert y[0] == x[-1]
+    assert np.array_equal(O.generate("text", 4096, 1, off=n - 4096), x[-4096:])
+    hx = sum(np.bincount(x[i:i + (1 << 30)], minlength=256) for i in range(0, n, 1 << 30))
+    hy = sum(np.bincount(y[i:i + (1 << 30)], minlength=256) for i in range(0, n, 1 << 30))
+    assert np.array_equal(hx, hy)
+    print("6 GiB text: forward %.0f ms, tied %d, rounds %d, factors %d" % (t.total_ms, t.active_after_round0, t.rounds, t.factors))
+    ctx.release_memory()
 
 
 def test_lf_walk_checker_on_small_input():

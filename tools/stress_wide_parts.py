@@ -6,7 +6,7 @@ forward against the oracle.  An input with a group larger than a part is refused
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["BWTS_TEST_KNOBS"] = "1"; os.environ["BWTS_FORCE_WIDE"] = "2"; os.environ["BWTS_WIDE_SEG_LOG2"] = "13"
+os.environ["BWTS_TEST_KNOBS"] = "1"; os.environ["BWTS_FORCE_WIDE"] = "2"; os.environ["BWTS_WIDE_SEG_LOG2"] = "13"; os.environ["BWTS_WIDE_DIRECT"] = "0"
 import numpy as np
 import oracle_lib as O
 import __graft_entry__ as ge
