@@ -268,6 +268,19 @@ struct WideRestOut {
 #define WIDE_DIRECT_MAX   (1ull << 22)
 #define WIDE_DIRECT_GROUP 32
 #define WIDE_DIRECT_DEPTH 4096ull
+// sampled keys of one segment, sorted: how many neighbours are equal?  (Two in 2^20 already mean millions of ties in 2^33 positions.)
+__global__ __launch_bounds__(256) void wide_sample_keys_kernel(const u64 *__restrict__ keys, u64 count, u32 samples, u64 *__restrict__ out, u32 *__restrict__ vals)
+{
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i < samples) { out[i] = keys[(u64)i * (count / samples)]; vals[i] = i; }
+}
+__global__ __launch_bounds__(256) void wide_sample_ties_kernel(const u64 *__restrict__ sorted, u32 samples, u64 *__restrict__ ties)
+{
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    const bool eq = i + 1 < samples && sorted[i] == sorted[i + 1];
+    const u64 m = __ballot(eq);
+    if (m && lane_id() == __ffsll((unsigned long long)m) - 1) atomicAdd((unsigned long long *)ties, (unsigned long long)__popcll(m));
+}
 struct WideGroupIn {
     TiedList tl;
     __device__ __forceinline__ u32 operator()(u64 i) const { return (i == 0 || tl.head(i) != tl.head(i - 1)) ? 1u : 0u; }
@@ -431,6 +444,27 @@ static int forward_wide_run(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out, bool
     for (u64 s = 0; s < nseg; s++)
         BWTS_TRY(launch_keybuild0_seg(ctx, d_T, n, al, segkeys, tile_min + s * (seg / KB_TILE), false, s * seg, seg_count(s)));
     u64 *cnt = ctx->d_small + SM_COUNTERS;
+    if (direct && kn.direct < 0) {
+        // is this an input with few ties at all?  2^20 of the last segment's keys (still in segkeys), sorted: text shows 10^5 equal
+        // neighbours, i.i.d. data none.  Two or more: the rank array is needed, and the caller is told before a bucket is sorted.
+        const u64 c = seg_count(nseg - 1);
+        const u32 m = c >= (1u << 20) ? (1u << 20) : (u32)c;
+        if (m >= 4096 && m <= Mb) {
+            HIPC(hipMemsetAsync(cnt + 27, 0, sizeof(u64), ctx->stream));
+            wide_sample_keys_kernel<<<dim3((m + 255) / 256), dim3(256), 0, ctx->stream>>>(segkeys, c, m, bk[0], bv[0]);
+            HIPC(hipGetLastError());
+            SortPlan spn;
+            spn.keys[0] = bk[0]; spn.keys[1] = bk[1];
+            spn.vals[0] = bv[0]; spn.vals[1] = bv[1];
+            spn.tile_hist = tile_hist; spn.scan_temp = scan_temp;
+            int sres = 0;
+            BWTS_TRY(radix_sort_pairs(ctx, spn, m, al.key_bits, &sres));
+            wide_sample_ties_kernel<<<dim3((m + 255) / 256), dim3(256), 0, ctx->stream>>>(spn.keys[sres], m, cnt + 27);
+            HIPC(hipGetLastError());
+            BWTS_TRY(read_small(ctx, SM_COUNTERS + 27, 1));
+            if (ctx->h_small[SM_COUNTERS + 27] >= 2) { *again = true; return BWTS_OK; }
+        }
+    }
     HIPC(hipMemsetAsync(cnt + 4, 0, 4 * sizeof(u64), ctx->stream));
     {
         SpanGuard g(ctx, BWTS_K_LYNDON, n, 0);
@@ -749,7 +783,7 @@ static int forward_wide_impl(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out)
     bool again = false;
     if (kn.direct != 0) {
         // first without the rank array: an input with few ties never needs it (8 n bytes, n random writes); one with many says so
-        // after its first bucket
+        // after a look at a sample of its keys, or at the latest when its tied list passes WIDE_DIRECT_MAX
         const int rc = forward_wide_run(ctx, d_T, n, d_out, true, &again);
         if (rc != BWTS_OK || !again) return rc;
         if (kn.direct == 1) return BWTS_E_RANGE;          // (forced: the tests want to know that this form did it)

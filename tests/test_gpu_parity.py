@@ -830,8 +830,8 @@ def test_wide_12GiB_dna_round_trip(ctx, pkg):
 
 def test_wide_6GiB_text_round_trip(ctx, pkg):
     """text(6 GiB): beyond 2^32 positions with 71 % of them tied after the first sort (4.6 * 10^9): the tied list in blocks taken as it
-    grows, the rounds over it part by part (three parts per round at first), 64-bit ranks.  The forward first tries without the rank
-    array and is told after its first bucket that this input needs it.  Round trip exact on the device, the bytes a permutation of
+    grows, the rounds over it part by part (three parts per round at first), 64-bit ranks.  A sample of the keys tells the forward that this input
+    needs the rank array (i.i.d. data runs without).  Round trip exact on the device, the bytes a permutation of
     the input's, bwts[0] = T[n-1]."""
     n = 6 << 30
     ctx.release_memory()                     # (what earlier tests left with the context: this case takes 215 GiB of its own)
