@@ -1,5 +1,5 @@
-# GPU session r03final: the numbers and profiles kept under profiles/ (round 3)
-O=gpurun_out/r03final; mkdir -p $O
+# GPU session r03final (run again as r03final2 after the WIDE chunks and the wide forward without ranks): the numbers and profiles kept under profiles/ (round 3)
+O=gpurun_out/r03final2; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
 timeout -k 10 200 python bench.py --workload uniform256 --log2n 28 --steps 10 --warmup 3 --no-cpu-baseline --no-e2e --no-text > $O/bench_c2.json 2> $O/bench_c2.err; echo "c2 rc=$?"
