@@ -2808,7 +2808,7 @@ static int lyndon_mode(const bwts_ctx *ctx)
 
 // Finds the factors and leaves the cyclic round-0 keys in sp.keys[0] / identity in sp.vals[0].
 static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, Alphabet *al, u32 **d_fstart, u64 *k_out,
-                            u32 *lyndon_rounds)
+                            u32 *lyndon_rounds, bool hist_ready = false)
 {
     u64 *cand[2];
     u32 *cvals[2];
@@ -2820,7 +2820,7 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
     u32 *fast_starts = arena_array<u32>(ctx, LYN_CAND_CAP);
     if (!fast_starts) return BWTS_E_NOMEM;
 
-    BWTS_TRY(read_histogram(ctx, d_T, n));
+    if (!hist_ready) BWTS_TRY(read_histogram(ctx, d_T, n));
     const int mode = lyndon_mode(ctx);
     bool done = false;
     *lyndon_rounds = 0;
@@ -2957,6 +2957,20 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
         const int rc = forward_wide_impl(ctx, d_in, n, d_out);
         if (n > 0x100000000ull || force_wide == 2 || rc != BWTS_E_RANGE) return rc;
     }
+    // one byte value only: n factors of one symbol, every rotation equal -- the transform is the identity (mk_bwts_sa.c:172-188 emits
+    // each factor's own last byte).  Taken before anything is allocated: at n = 2^32 this is the input on which every position stays
+    // tied, which the tied-list buffers (32-bit slots) cannot hold.
+    BWTS_TRY(read_histogram(ctx, d_in, n));
+    {
+        int present = 0;
+        for (int c = 0; c < 256; c++) present += ctx->h_small[SM_HIST + c] ? 1 : 0;
+        if (present == 1) {
+            HIPC(hipMemcpyAsync(d_out, d_in, n, hipMemcpyDeviceToDevice, ctx->stream));
+            ctx->tm.factors = n; ctx->tm.rounds = 1; ctx->tm.lyndon_rounds = 0; ctx->tm.active_after_round0 = 0;
+            ctx->tm.key_symbols = 1; ctx->tm.key_bits = 1;
+            return BWTS_OK;
+        }
+    }
     BWTS_TRY(arena_reserve(ctx, forward_arena_bytes(n)));
     SortSpace sp;
     BWTS_TRY(sort_space_alloc(ctx, n, &sp));
@@ -2969,7 +2983,7 @@ int forward_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     const char *emit_env = bwts_knob(ctx, "BWTS_EMIT");      // carry (default) | gather
     const bool carry = radix_supports_sym(ctx) && !(emit_env && !strcmp(emit_env, "gather"));
     sp.want_split = carry;                           // the byte stream rides round 0 => the packed passes may take split keys
-    BWTS_TRY(factors_and_keys(ctx, d_in, n, sp, &al, &d_fstart, &k, &lrounds));
+    BWTS_TRY(factors_and_keys(ctx, d_in, n, sp, &al, &d_fstart, &k, &lrounds, true));
     ctx->tm.factors = k;
     ctx->tm.lyndon_rounds = lrounds;
     ctx->tm.key_symbols = (u32)al.msym;

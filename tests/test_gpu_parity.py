@@ -432,6 +432,28 @@ def test_index_boundary_2p31(ctx):
     _properties_at_scale(ctx, rec["kind"], n, rec["seed"])
 
 
+def test_constant_input_at_2p32(ctx):
+    """4 GiB of one byte value: n = 2^32 factors of one symbol, every rotation equal -- the one input on which every position stays
+    tied at the largest size the 32-bit paths take.  mk_bwts_sa.c:172-188 emits each factor's own last byte: the transform is the
+    identity, both ways; small sizes alongside, against the oracle."""
+    for m in (1, 7, 100000):
+        x = np.full(m, 200, dtype=np.uint8)
+        assert np.array_equal(ctx.forward(x), O.forward(x)) and np.array_equal(ctx.inverse(x), x)
+    n = 1 << 32
+    x = np.full(n, 97, dtype=np.uint8)
+    d_in, d_out = ctx.alloc(n), ctx.alloc(n)
+    try:
+        d_in.upload(x)
+        ctx.forward_device(d_in, n, d_out)
+        assert ctx.timings().factors == n
+        assert ctx.device_equal(d_in, d_out, n)
+        ctx.inverse_device(d_in, n, d_out)
+        assert ctx.device_equal(d_in, d_out, n)
+    finally:
+        d_in.free()
+        d_out.free()
+
+
 def test_config4_dna_4GiB_properties(ctx, pkg):
     """BASELINE config 4: dna(2^32).  Beyond the reference's 32-bit indices (mk_bwts_sa.c:26-27, unbwts.c:12-13), so parity
     is by properties only: round trip both ways, byte histogram preserved, bwts[0] = T[n-1]."""
