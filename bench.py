@@ -147,6 +147,32 @@ def _per_kernel(a):
     return out
 
 
+def _real_text(ctx, d_in, d_out, d_back, cap):
+    """53.6 MiB of real text through the device path: best of 5 forwards and inverses (wall time per synchronous call), round trip."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from realtext import corpus
+    x = np.frombuffer(corpus(1 << 26), dtype=np.uint8)
+    m = int(x.size)
+    if m < (1 << 20) or m > cap:
+        return {"skipped": "corpus of %d bytes" % m}
+    d_in.upload(x)
+    ctx.set_timing(0)
+    ctx.forward_device(d_in, m, d_out)
+    tf, ti = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); ctx.forward_device(d_in, m, d_out); tf.append(time.perf_counter() - t0)
+    info = ctx.timings().as_dict()
+    ctx.inverse_device(d_out, m, d_back)
+    for _ in range(5):
+        t0 = time.perf_counter(); ctx.inverse_device(d_out, m, d_back); ti.append(time.perf_counter() - t0)
+    return {"workload": "source and documentation files of this image, concatenated (tests/realtext.py)", "bytes": m,
+            "sha256_in": hashlib.sha256(x.tobytes()).hexdigest(),
+            "forward_ms": round(1e3 * min(tf), 2), "forward_MBps": round(m / 1e6 / min(tf), 1),
+            "inverse_ms": round(1e3 * min(ti), 2), "inverse_MBps": round(m / 1e6 / min(ti), 1),
+            "roundtrip_exact": bool(ctx.device_equal(d_in, d_back, m)), "rounds": info["rounds"], "tied_after_round0": info["active_after_round0"]}
+
+
 def _pmc_traffic(kernel_prefix, workload, log2n, source_file, per_elem=None):
     """HBM bytes of a kernel from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*.json, made by
     tools/pmc_summary.py).  A record names the kernel, the workload and the sha256 of the source file the kernel lives in: a
@@ -488,6 +514,14 @@ def main(argv=None):
                         "HIP events on the engine's stream inside the timed region of the text leg (2 forwards)", per_forward=2)
                 if not t["roundtrip"]:
                     bad = 1.0
+                # real text beside the synthetic one (the reference's own workload is enwik8, Makefile:35-38, which no box has): source and
+                # documentation files of this image, as in the gpu suite (tests/realtext.py builds it; no oracle involved here)
+                try:
+                    line["text"]["real"] = _real_text(ctx, d_in, d_out, d_back, n)
+                    if line["text"]["real"].get("roundtrip_exact") is False:
+                        bad = 1.0
+                except Exception as e:
+                    line["text"]["real"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_log2n)
         print(json.dumps(line), flush=True)
