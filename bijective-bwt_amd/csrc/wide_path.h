@@ -386,7 +386,10 @@ static int forward_wide_run(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out, bool
     // larger buckets (fewer collection passes over the text) while rank array + bucket buffers + in/out leave room: 12 GiB of DNA
     // take 2.03 s with buckets of 2^30 elements (before the carried byte), 1.86 s with 2^31, 1.62 s with 3 * 2^30 (203 GiB on the device)
     if (!bwts_knob(ctx, "BWTS_WIDE_BUCKET")) {
-        if (n <= (13ull << 30) || (direct && n <= (48ull << 30))) kn.bucket_cap = 3ull << 30;
+        // (without the rank array there is room for the largest bucket the 32-bit sort indices allow: 4 instead of 5 passes over the
+        // text at 12 GiB, 7 instead of 9 at 24 GiB)
+        if (direct && n <= (48ull << 30)) kn.bucket_cap = 0xff000000ull;
+        else if (n <= (13ull << 30)) kn.bucket_cap = 3ull << 30;
         else if (n <= (14ull << 30) || direct) kn.bucket_cap = 1ull << 31;
     }
     const u64 seg = 1ull << kn.seg_log2;
