@@ -432,6 +432,28 @@ def test_index_boundary_2p31(ctx):
     _properties_at_scale(ctx, rec["kind"], n, rec["seed"])
 
 
+def test_device_entry_points_take_pinned_host_memory(ctx):
+    """bwts_forward_device / bwts_inverse_device with input and output in pinned host memory (bwts_host_alloc): the kernels read the
+    text and write the result over PCIe, only the working buffers live on the device -- the route for inputs whose in/out copies do
+    not fit beside the working set.  Same bytes as the oracle's."""
+    n = (1 << 25) + 777
+    x = O.generate("zipf", n, 31)
+    want = O.forward(x)
+    hin, pin = ctx.host_alloc(n)
+    hout, pout = ctx.host_alloc(n)
+    try:
+        hin[:] = x
+        ctx.forward_device(pin, n, pout)
+        assert np.array_equal(hout, want)
+        hin[:] = want
+        hout[:] = 0
+        ctx.inverse_device(pin, n, pout)
+        assert np.array_equal(hout, x)
+    finally:
+        ctx.host_free(pin)
+        ctx.host_free(pout)
+
+
 def test_constant_input_at_2p32(ctx):
     """4 GiB of one byte value: n = 2^32 factors of one symbol, every rotation equal -- the one input on which every position stays
     tied at the largest size the 32-bit paths take.  mk_bwts_sa.c:172-188 emits each factor's own last byte: the transform is the
