@@ -1035,13 +1035,15 @@ def test_text_1GiB_golden_and_properties(ctx):
     {"BWTS_POISON": "1", "BWTS_DENSE": "tiles"},
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_alternate_paths(env):
-    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+    # (-s: the child must not capture its tests' stderr -- what the HIP runtime says when it aborts the process would stay in the capture file)
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-s",
            "-k", "(small or mid_size or deep_repeats or dense_ties or dense_rounds or chunk_rounds or text_16MiB or reference_unbwts_vectors_through_cabi) and not alternate"]
     # (-k matches case-insensitively and looks at parameter ids too: without the exclusion, an id like BWTS_RX_SMALL=0
     # makes the child select this very test and start a child of its own.)
     if os.environ.get("BWTS_TEST_CHILD"):
         pytest.skip("already inside a child run")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, BWTS_TEST_CHILD="1", BWTS_TEST_KNOBS="1", **env), cwd=ROOT)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                            env=dict(os.environ, BWTS_TEST_CHILD="1", BWTS_TEST_KNOBS="1", LIBC_FATAL_STDERR_="1", **env), cwd=ROOT)
     try:
         out, _ = proc.communicate(timeout=900)
     except subprocess.TimeoutExpired:
