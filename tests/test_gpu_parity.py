@@ -1007,6 +1007,34 @@ def test_text_1GiB_golden_and_properties(ctx):
 # ---------------------------------------------------------------------------------------------
 # alternate code paths, selected by environment knobs (read once per context, and only under BWTS_TEST_KNOBS=1 -> one child process per mode)
 # ---------------------------------------------------------------------------------------------
+def test_stray_knobs_are_ignored_without_the_gate(pkg):
+    """A process that merely inherits BWTS_* variables runs the product paths: the switches for alternate code paths count only
+    under BWTS_TEST_KNOBS=1, and a context reads its environment once, when it is made."""
+    x = O.generate("zipf", 200000, 77)
+    os.environ["BWTS_FORCE_WIDE"] = "2"
+    os.environ["BWTS_KEY_BITS"] = "16"
+    try:
+        with pkg.Context(0) as c:
+            y = c.forward(x)
+            t = c.timings()
+            assert t.key_bits > 16                             # not the forced width: the knob was not looked at
+            assert np.array_equal(y, O.forward(x))
+        os.environ["BWTS_TEST_KNOBS"] = "1"
+        del os.environ["BWTS_FORCE_WIDE"]
+        with pkg.Context(0) as c:
+            y = c.forward(x)
+            assert c.timings().key_bits == 16 and np.array_equal(y, O.forward(x))
+    finally:
+        for k in ("BWTS_FORCE_WIDE", "BWTS_KEY_BITS", "BWTS_TEST_KNOBS"):
+            os.environ.pop(k, None)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
+
+
+# (last in the file: should one of these children die -- DESIGN.md section 9 -- every other test of the suite has run by then)
 @pytest.mark.parametrize("env", [
     {"BWTS_VARLEN": "1", "BWTS_KEY_BITS": "24"},      # variable-length key codes on every input, narrow keys: many ties, sparse ranks
     {"BWTS_VARLEN": "1", "BWTS_KEY_BITS": "64"},
@@ -1051,30 +1079,3 @@ def test_alternate_paths(env):
         out, _ = proc.communicate()
     _wait_gpu_handle_released(proc.pid)
     assert proc.returncode == 0, _child_report("alternate_" + ",".join("%s=%s" % kv for kv in env.items()), out)
-
-
-def test_stray_knobs_are_ignored_without_the_gate(pkg):
-    """A process that merely inherits BWTS_* variables runs the product paths: the switches for alternate code paths count only
-    under BWTS_TEST_KNOBS=1, and a context reads its environment once, when it is made."""
-    x = O.generate("zipf", 200000, 77)
-    os.environ["BWTS_FORCE_WIDE"] = "2"
-    os.environ["BWTS_KEY_BITS"] = "16"
-    try:
-        with pkg.Context(0) as c:
-            y = c.forward(x)
-            t = c.timings()
-            assert t.key_bits > 16                             # not the forced width: the knob was not looked at
-            assert np.array_equal(y, O.forward(x))
-        os.environ["BWTS_TEST_KNOBS"] = "1"
-        del os.environ["BWTS_FORCE_WIDE"]
-        with pkg.Context(0) as c:
-            y = c.forward(x)
-            assert c.timings().key_bits == 16 and np.array_equal(y, O.forward(x))
-    finally:
-        for k in ("BWTS_FORCE_WIDE", "BWTS_KEY_BITS", "BWTS_TEST_KNOBS"):
-            os.environ.pop(k, None)
-
-
-def test_smoke_entry():
-    import __graft_entry__ as ge
-    ge.smoke()
