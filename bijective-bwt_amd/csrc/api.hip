@@ -62,14 +62,98 @@ const char *bwts_knob(const bwts_ctx *ctx, const char *name)
 // nothing has written yet does so reproducibly -- whatever an earlier call or process left there -- instead of once in a blue moon
 static bool poison_on(const bwts_ctx *ctx) { const char *e = bwts_knob(ctx, "BWTS_POISON"); return e && e[0] == '1'; }
 
+// device blocks of the context, with guard bands when BWTS_GUARD=1
+#define GUARD_BYTE 0x5C
+#define GUARD_FREED 0x5D
+// BWTS_TRACE_ALLOC=1: every block the context takes or gives up, with its address range, on stderr -- the map a GPU memory fault's
+// address is read against
+static void trace_alloc(const bwts_ctx *ctx, const char *what, const char *name, const void *p, size_t bytes)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("BWTS_TRACE_ALLOC"); on = (e && e[0] == '1') ? 1 : 0; }
+    if (on) fprintf(stderr, "[bwts alloc] ctx %p %s %-16s [%p, %p) %zu bytes\n", (const void *)ctx, what, name, p, (const void *)((const char *)p + bytes), bytes);
+}
+static hipError_t ctx_malloc(bwts_ctx *ctx, void **out, size_t bytes, const char *name)
+{
+    if (!ctx->guard) { const hipError_t e0 = hipMalloc(out, bytes); if (e0 == hipSuccess) trace_alloc(ctx, "device +", name, *out, bytes); return e0; }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes + 2 * ctx->guard);
+    if (e != hipSuccess) return e;
+    e = hipMemset(p, GUARD_BYTE, ctx->guard);
+    if (e == hipSuccess) e = hipMemset((char *)p + ctx->guard + bytes, GUARD_BYTE, ctx->guard);
+    if (e != hipSuccess) { (void)hipFree(p); return e; }
+    *out = (char *)p + ctx->guard;
+    ctx->guard_blocks.push_back({(char *)*out, bytes, name});
+    return hipSuccess;
+}
+static hipError_t ctx_free(bwts_ctx *ctx, void *user)
+{
+    trace_alloc(ctx, "device -", "", user, 0);
+    if (!ctx->guard) return hipFree(user);
+    for (size_t i = 0; i < ctx->guard_blocks.size(); i++)
+        if (ctx->guard_blocks[i].user == (char *)user) {
+            const bwts_ctx::GuardBlock b = ctx->guard_blocks[i];
+            ctx->guard_blocks.erase(ctx->guard_blocks.begin() + (long)i);
+            // blocks of up to 64 MiB are not handed back: they stay mapped, filled with a pattern that guard_check() looks at
+            if (b.bytes <= ((size_t)64 << 20) && hipDeviceSynchronize() == hipSuccess &&
+                hipMemset((char *)user - ctx->guard, GUARD_FREED, b.bytes + 2 * ctx->guard) == hipSuccess) {
+                ctx->guard_freed.push_back(b);
+                return hipSuccess;
+            }
+            break;
+        }
+    return hipFree((char *)user - ctx->guard);
+}
+// after a transform: are all guard bands intact?
+static int guard_check(bwts_ctx *ctx, const char *what)
+{
+    if (!ctx->guard) return BWTS_OK;
+    std::vector<unsigned char> h(ctx->guard);
+    int bad = 0;
+    for (const auto &b : ctx->guard_blocks)
+        for (int side = 0; side < 2; side++) {
+            const char *src = side == 0 ? b.user - ctx->guard : b.user + b.bytes;
+            HIPC(hipMemcpy(h.data(), src, ctx->guard, hipMemcpyDeviceToHost));
+            size_t first = ctx->guard, last = 0, count = 0;
+            for (size_t i = 0; i < ctx->guard; i++)
+                if (h[i] != GUARD_BYTE) { if (first == ctx->guard) first = i; last = i; count++; }
+            if (count) {
+                bad++;
+                fprintf(stderr, "[bwts guard] %s: block '%s' (%zu bytes): %zu byte(s) written %s it, offsets %ld .. %ld relative to the block's %s; first bytes:", what,
+                        b.name, b.bytes, count, side == 0 ? "IN FRONT OF" : "BEHIND", side == 0 ? (long)first - (long)ctx->guard : (long)first,
+                        side == 0 ? (long)last - (long)ctx->guard : (long)last, side == 0 ? "start" : "end");
+                for (size_t i = first; i < first + 16 && i < ctx->guard; i++) fprintf(stderr, " %02x", h[i]);
+                fprintf(stderr, "\n");
+                HIPC(hipMemset((void *)src, GUARD_BYTE, ctx->guard));
+            }
+        }
+    for (const auto &b : ctx->guard_freed) {
+        const size_t total = b.bytes + 2 * ctx->guard;
+        std::vector<unsigned char> f(total);
+        HIPC(hipMemcpy(f.data(), b.user - ctx->guard, total, hipMemcpyDeviceToHost));
+        size_t first = total, last = 0, count = 0;
+        for (size_t i = 0; i < total; i++)
+            if (f[i] != GUARD_FREED) { if (first == total) first = i; last = i; count++; }
+        if (count) {
+            bad++;
+            fprintf(stderr, "[bwts guard] %s: GIVEN-UP block '%s' (%zu bytes) was written after the context let go of it: %zu byte(s), offsets %ld .. %ld from its start; first bytes:",
+                    what, b.name, b.bytes, count, (long)first - (long)ctx->guard, (long)last - (long)ctx->guard);
+            for (size_t i = first; i < first + 16 && i < total; i++) fprintf(stderr, " %02x", f[i]);
+            fprintf(stderr, "\n");
+            HIPC(hipMemset(b.user - ctx->guard, GUARD_FREED, total));
+        }
+    }
+    return bad ? BWTS_E_INTERNAL : BWTS_OK;
+}
+
 int arena_reserve(bwts_ctx *ctx, size_t bytes)
 {
     bytes = align_up(bytes, 1 << 20);
     if (bytes > ctx->arena_cap) {
         const double t0 = wall_ms();
-        if (ctx->arena) { HIPC(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
+        if (ctx->arena) { HIPC(ctx_free(ctx, ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
         void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+        if (ctx_malloc(ctx, &p, bytes, "arena") != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
         ctx->arena = (char *)p;
         ctx->arena_cap = bytes;
         ctx->host_ms[BWTS_H_ARENA_ALLOC] += wall_ms() - t0;
@@ -96,9 +180,10 @@ int aux_reserve_slot(bwts_ctx *ctx, int slot, size_t bytes, char **base)
     if (bytes > ctx->aux_cap[slot]) {
         const double t0 = wall_ms();
         // contents of a previous, smaller block are never live across this call
-        if (ctx->aux[slot]) { HIPC(hipStreamSynchronize(ctx->stream)); HIPC(hipFree(ctx->aux[slot])); ctx->aux[slot] = nullptr; ctx->aux_cap[slot] = 0; }
+        if (ctx->aux[slot]) { HIPC(hipStreamSynchronize(ctx->stream)); HIPC(ctx_free(ctx, ctx->aux[slot])); ctx->aux[slot] = nullptr; ctx->aux_cap[slot] = 0; }
         void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+        static const char *const aux_names[BWTS_AUX_SLOTS] = {"side block 0", "side block 1", "side block 2", "side block 3", "side block 4"};
+        if (ctx_malloc(ctx, &p, bytes, aux_names[slot]) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
         ctx->aux[slot] = (char *)p;
         ctx->aux_cap[slot] = bytes;
         ctx->host_ms[BWTS_H_ARENA_ALLOC] += wall_ms() - t0;
@@ -191,13 +276,15 @@ extern "C" int bwts_ctx_create(bwts_ctx **out, int device_id)
     ctx->device = device_id;
     read_knobs(ctx);
     { const char *e = bwts_knob(ctx, "BWTS_TIMINGS"); ctx->timing = (e && e[0] == '1') ? 2 : 0; }
+    { const char *e = bwts_knob(ctx, "BWTS_GUARD"); ctx->guard = (e && e[0] == '1') ? ((size_t)1 << 20) : 0; }
     if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return BWTS_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BWTS_E_HIP; }
     void *p = nullptr;
-    if (hipMalloc(&p, 4096 * sizeof(u64)) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_NOMEM; }
+    if (ctx_malloc(ctx, &p, 4096 * sizeof(u64), "small words") != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_NOMEM; }
     ctx->d_small = (u64 *)p;
     if (hipMemset(p, 0, 4096 * sizeof(u64)) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_HIP; }     // (counters that kernels expect at zero)
     if (hipHostMalloc(&p, 4096 * sizeof(u64), hipHostMallocDefault) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_NOMEM; }
+    trace_alloc(ctx, "pinned +", "small words", p, 4096 * sizeof(u64));
     ctx->h_small = (u64 *)p;
     if (hipEventCreate(&ctx->ev_begin) != hipSuccess || hipEventCreate(&ctx->ev_end) != hipSuccess) { bwts_ctx_destroy(ctx); return BWTS_E_HIP; }
     ctx->host_ms[BWTS_H_INIT] = wall_ms() - t_create;
@@ -213,10 +300,12 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
-    if (ctx->arena) (void)hipFree(ctx->arena);
-    for (int i = 0; i < BWTS_AUX_SLOTS; i++) if (ctx->aux[i]) (void)hipFree(ctx->aux[i]);
+    if (ctx->arena) (void)ctx_free(ctx, ctx->arena);
+    for (int i = 0; i < BWTS_AUX_SLOTS; i++) if (ctx->aux[i]) (void)ctx_free(ctx, ctx->aux[i]);
     for (char *b : ctx->tied_blk) (void)hipFree(b);
-    if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->d_small) (void)ctx_free(ctx, ctx->d_small);
+    for (const auto &b : ctx->guard_freed) (void)hipFree(b.user - ctx->guard);
+    ctx->guard_freed.clear();
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     for (Stager &sg : ctx->stg) {
         if (sg.pool) { sg.pool->shutdown(); delete sg.pool; }
@@ -228,7 +317,7 @@ extern "C" void bwts_ctx_destroy(bwts_ctx *ctx)
         if (sg.copy_stream) (void)hipStreamDestroy(sg.copy_stream);
         if (sg.own_stream && sg.stream) (void)hipStreamDestroy(sg.stream);
     }
-    for (int i = 0; i < 4; i++) if (ctx->d_io[i]) (void)hipFree(ctx->d_io[i]);
+    for (int i = 0; i < 4; i++) if (ctx->d_io[i]) (void)ctx_free(ctx, ctx->d_io[i]);
     for (const auto &b : ctx->host_blocks) (void)hipHostFree(b.first);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -241,13 +330,13 @@ extern "C" int bwts_ctx_release_memory(bwts_ctx *ctx)
     if (!ctx) return BWTS_E_ARG;
     HIPC(hipSetDevice(ctx->device));
     HIPC(hipStreamSynchronize(ctx->stream));
-    if (ctx->arena) { HIPC(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; ctx->arena_off = 0; }
+    if (ctx->arena) { HIPC(ctx_free(ctx, ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; ctx->arena_off = 0; }
     for (int i = 0; i < BWTS_AUX_SLOTS; i++)
-        if (ctx->aux[i]) { HIPC(hipFree(ctx->aux[i])); ctx->aux[i] = nullptr; ctx->aux_cap[i] = 0; }
+        if (ctx->aux[i]) { HIPC(ctx_free(ctx, ctx->aux[i])); ctx->aux[i] = nullptr; ctx->aux_cap[i] = 0; }
     for (char *b : ctx->tied_blk) HIPC(hipFree(b));
     ctx->tied_blk.clear();
     for (int i = 0; i < 4; i++)
-        if (ctx->d_io[i]) { HIPC(hipFree(ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
+        if (ctx->d_io[i]) { HIPC(ctx_free(ctx, ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
     return BWTS_OK;
 }
 
@@ -274,6 +363,11 @@ static int run_device(bwts_ctx *ctx, device_impl_fn fn, const void *d_in, u64 n,
     }
     HIPC(hipEventRecord(ctx->ev_begin, ctx->stream));
     int rc = fn(ctx, (const u8 *)d_in, n, (u8 *)d_out);
+    if (ctx->guard) {
+        (void)hipStreamSynchronize(ctx->stream);
+        const int grc = guard_check(ctx, fn == forward_device_impl ? "forward" : "inverse");
+        if (rc == BWTS_OK) rc = grc;
+    }
     if (rc != BWTS_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     HIPC(hipEventRecord(ctx->ev_end, ctx->stream));
     BWTS_TRY(spans_resolve(ctx));
@@ -439,6 +533,7 @@ static int ensure_staging(bwts_ctx *ctx, Stager &sg)
             void *p = nullptr;
             if (hipHostMalloc(&p, STAGE_CHUNK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
             sg.pinned[i] = (char *)p;
+            trace_alloc(ctx, "pinned +", "staging slot", p, STAGE_CHUNK);
         }
         if (!sg.slot_ev[i]) HIPC(hipEventCreateWithFlags(&sg.slot_ev[i], hipEventDisableTiming));
         if (!sg.slot_ev2[i]) HIPC(hipEventCreateWithFlags(&sg.slot_ev2[i], hipEventDisableTiming));
@@ -543,10 +638,11 @@ static int ensure_io(bwts_ctx *ctx, u64 n, bool pairs)
     for (int i = 0; i < 4; i++) {
         if (!pairs && (i & 1)) continue;
         if (ctx->d_io_cap[i] >= n) continue;
-        if (ctx->d_io[i]) { HIPC(hipFree(ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
+        if (ctx->d_io[i]) { HIPC(ctx_free(ctx, ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
         void *p = nullptr;
         const size_t cap = align_up((size_t)n, 1 << 20);
-        if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
+        static const char *const io_names[4] = {"device input 0", "device input 1", "device output 0", "device output 1"};
+        if (ctx_malloc(ctx, &p, cap, io_names[i]) != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
         ctx->d_io[i] = (u8 *)p;
         ctx->d_io_cap[i] = cap;
     }
@@ -564,6 +660,8 @@ static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_
     if (!ctx || !in || (!out && !sink) || n == 0) return BWTS_E_ARG;
     HIPC(hipSetDevice(ctx->device));
     BWTS_TRY(ensure_io(ctx, n, false));
+    trace_alloc(ctx, "call    ", fn == forward_device_impl ? "forward: in" : "inverse: in", in, n);
+    if (out) trace_alloc(ctx, "call    ", "out", out, n);
     Stager &sg = ctx->stg[0];
     // a context's first call allocates its arena, which can cost as long as the whole input copy (the driver clears what it hands
     // out): a helper thread does it while this one stages the input

@@ -80,6 +80,12 @@ struct bwts_ctx {
     // list grows and kept for the next call
     std::vector<char *> tied_blk;
     int tied_blk_lg = 0;
+    // BWTS_GUARD=1 (a test switch): every block the context takes from the device gets `guard` bytes of a fixed pattern in front and
+    // behind, checked after every transform: a kernel that writes outside its buffers is named, with the block and the offset
+    size_t guard = 0;
+    struct GuardBlock { char *user; size_t bytes; const char *name; };
+    std::vector<GuardBlock> guard_blocks;
+    std::vector<GuardBlock> guard_freed;         // ... and what the context has given up stays mapped, filled with a second pattern: a write through a stale pointer shows
 
     // small pinned host block for read-backs, and a device mirror
     u64 *h_small;          // 4096 u64

@@ -1071,7 +1071,7 @@ def test_alternate_paths(env):
     if os.environ.get("BWTS_TEST_CHILD"):
         pytest.skip("already inside a child run")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                            env=dict(os.environ, BWTS_TEST_CHILD="1", BWTS_TEST_KNOBS="1", LIBC_FATAL_STDERR_="1", **env), cwd=ROOT)
+                            env=dict(os.environ, BWTS_TEST_CHILD="1", BWTS_TEST_KNOBS="1", LIBC_FATAL_STDERR_="1", BWTS_TRACE_ALLOC="1", **env), cwd=ROOT)
     try:
         out, _ = proc.communicate(timeout=900)
     except subprocess.TimeoutExpired:
