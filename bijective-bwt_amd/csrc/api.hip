@@ -276,7 +276,7 @@ extern "C" int bwts_ctx_create(bwts_ctx **out, int device_id)
     ctx->device = device_id;
     read_knobs(ctx);
     { const char *e = bwts_knob(ctx, "BWTS_TIMINGS"); ctx->timing = (e && e[0] == '1') ? 2 : 0; }
-    { const char *e = bwts_knob(ctx, "BWTS_GUARD"); ctx->guard = (e && e[0] == '1') ? ((size_t)1 << 20) : 0; }
+    { const char *e = bwts_knob(ctx, "BWTS_GUARD"); const int mib = e ? atoi(e) : 0; ctx->guard = mib >= 1 && mib <= 256 ? ((size_t)mib << 20) : 0; }     // MiB per band
     if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return BWTS_E_NODEVICE; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return BWTS_E_HIP; }
     void *p = nullptr;
@@ -668,7 +668,8 @@ static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_
     const size_t want = arena_hint(fn, n);
     std::thread reserve;
     int reserve_rc = BWTS_OK;
-    if (want > ctx->arena_cap)
+    // (only where it can pay: a block of a few MiB is allocated by the transform itself, on this thread, as on the _device path)
+    if (want > ctx->arena_cap && want - ctx->arena_cap >= ((size_t)256 << 20))
         reserve = std::thread([ctx, want, &reserve_rc] { if (hipSetDevice(ctx->device) == hipSuccess) reserve_rc = arena_reserve(ctx, want); });
     double t0 = wall_ms();
     const int h2d_rc = staged_h2d(ctx, sg, ctx->d_io[0], in, n);
