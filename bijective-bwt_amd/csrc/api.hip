@@ -170,6 +170,7 @@ void *arena_alloc(bwts_ctx *ctx, size_t bytes)
     bytes = align_up(bytes ? bytes : 1, 256);
     if (ctx->arena_off + bytes > ctx->arena_cap) return nullptr;
     void *p = ctx->arena + ctx->arena_off;
+    trace_alloc(ctx, "  arena:", "array", p, bytes);
     ctx->arena_off += bytes;
     return p;
 }
