@@ -146,6 +146,16 @@ static int guard_check(bwts_ctx *ctx, const char *what)
     return bad ? BWTS_E_INTERNAL : BWTS_OK;
 }
 
+void bwts_stage_mark(bwts_ctx *ctx, const char *name)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("BWTS_STAGE_TRACE"); on = (e && e[0] == '1') ? 1 : 0; }
+    if (!on) return;
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    fprintf(stderr, "[bwts stage] %s %s\n", name, e == hipSuccess ? "ok" : "FAILED");
+    fflush(stderr);
+}
+
 int arena_reserve(bwts_ctx *ctx, size_t bytes)
 {
     bytes = align_up(bytes, 1 << 20);
@@ -676,6 +686,7 @@ static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_
     const int h2d_rc = staged_h2d(ctx, sg, ctx->d_io[0], in, n);
     if (reserve.joinable()) reserve.join();
     BWTS_TRY(h2d_rc);
+    STAGE("host path: input on the device");
     if (reserve_rc != BWTS_OK && reserve_rc != BWTS_E_NOMEM) return reserve_rc;       // (out of memory: the transform's own reservation reports it)
     const double h2d = wall_ms() - t0;
     // the caller's output buffer is usually fresh: its page faults are taken by the copy workers during the transform
@@ -684,6 +695,7 @@ static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_
     const int rcd = run_device(ctx, fn, ctx->d_io[0], n, ctx->d_io[2]);
     if (touch) sg.pool->wait();
     BWTS_TRY(rcd);
+    STAGE("host path: transform done");
     t0 = wall_ms();
     const int rc = staged_d2h(ctx, sg, out, ctx->d_io[2], n, sink, user);
     ctx->tm.d2h_ms = wall_ms() - t0;

@@ -2212,7 +2212,9 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         iota_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(sp.vals[0], n);
     }
     int res = 0;
+    STAGE("cyclic patch (before round 0)");
     BWTS_TRY(radix_sort_pairs(ctx, plan, n, al.key_bits, &res));
+    STAGE("round-0 sort");
     u64 *K0 = sp.keys[res];
     u32 *SA = sp.vals[res];
     // the other key buffer (8n bytes) and value buffer (4n) are free: first active list goes there
@@ -2253,6 +2255,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         BWTS_TRY((device_scan<false, u64>(ctx, words, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
         count_tied_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(keepw, pre, words, cnt + 0);
         HIPC(hipGetLastError());
+        STAGE("group flags + word scan + count");
         flag_keep = keepw; flag_words = words;
         flag_heads_any = headw; flag_pre_any = pre;
     }
@@ -2291,6 +2294,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         const unsigned blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
         tied_from_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(flag_heads_any, flag_keep, flag_pre_any, n, SA, cur.idx, cur.slot, cur.head, cnt + 0);
         HIPC(hipGetLastError());
+        STAGE("tied list");
     }
     sp.tie_slots = cur.slot;        // stays untouched by the later rounds
     sp.tie_count = a;
@@ -2830,8 +2834,11 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
         SampleScratch ss{d_T, {sp.keys[0], sp.keys[1]}, {sp.vals[0], sp.vals[1]}, sp.tile_hist, sp.scan_temp};
         BWTS_TRY(set_alphabet(ctx, false, n, al, &ss));
         sp.split_keys = sp.want_split && radix_packed_applicable(ctx, n, al->key_bits);
+        STAGE("histogram + alphabet");
         BWTS_TRY(launch_keybuild0(ctx, d_T, n, *al, sp, tile_min, sp.split_keys));
+        STAGE("keybuild0");
         BWTS_TRY(lyndon_fast(ctx, d_T, n, *al, sp, tile_min, cand, cvals, fast_starts, k_out, &done));
+        STAGE("lyndon_fast");
         if (done) *d_fstart = fast_starts;
         else if (mode == 1) return BWTS_E_INTERNAL;
     }
@@ -2846,6 +2853,7 @@ static int factors_and_keys(bwts_ctx *ctx, const u8 *d_T, u64 n, SortSpace &sp, 
     if (sp.split_keys) {
         carried_head_fix_kernel<<<dim3((unsigned)((*k_out + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_T, n, *d_fstart, *k_out, ks);
         HIPC(hipGetLastError());
+        STAGE("carried_head_fix");
     }
     // wrap the keys of positions near their factor's end
     if (al->varlen) {

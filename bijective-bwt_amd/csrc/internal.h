@@ -121,6 +121,11 @@ struct bwts_ctx {
     bool launched;                  // a kernel of this context has run (the code object is loaded)
 };
 
+// BWTS_STAGE_TRACE=1 (diagnosis): the stream is drained after every stage of a transform and the stage is named on stderr, so that
+// a GPU fault -- reported asynchronously -- is known to come from the stage after the last one named
+void bwts_stage_mark(bwts_ctx *ctx, const char *name);
+#define STAGE(name) bwts_stage_mark(ctx, name)
+
 #define HIPC(call)                                                        \
     do {                                                                  \
         hipError_t e__ = (call);                                          \

@@ -589,7 +589,9 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
         }
         {
             SpanGuard g(ctx, BWTS_K_RADIX_SCAN, tiles * 256, tiles * 256 * 12);
+            STAGE("packed pass: histogram");
             BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, plan.scan_temp));
+            STAGE("packed pass: column scan");
         }
         if (first) {
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (pass_bytes / 2 - 4 + pass_bytes / 2) * m);
@@ -604,6 +606,7 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
             BWTS_TRY((launch_scatter_packed<false, false, HI16>(ctx, tiles, io, tile_hist, m, shift)));
         }
         HIPC(hipGetLastError());
+        STAGE("packed pass: scatter");
         cur ^= 1;
     }
     *result_buf = cur;
