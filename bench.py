@@ -34,8 +34,11 @@ _HELPER = r'''
 import json, subprocess, sys, time
 for line in sys.stdin:
     req = json.loads(line)
+    env = req.get("env")
+    if env is not None:
+        env["BWTS_T0_NS"] = str(time.clock_gettime_ns(time.CLOCK_MONOTONIC))      # the CLI reports what passed before its main()
     t0 = time.perf_counter()
-    p = subprocess.run(req["cmd"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=req.get("env"))
+    p = subprocess.run(req["cmd"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     wall = time.perf_counter() - t0
     print(json.dumps({"rc": p.returncode, "wall_s": wall, "stderr": p.stderr.decode(errors="replace")[-2000:]}), flush=True)
 '''
@@ -173,12 +176,25 @@ def _real_text(ctx, d_in, d_out, d_back, cap):
             "roundtrip_exact": bool(ctx.device_equal(d_in, d_back, m)), "rounds": info["rounds"], "tied_after_round0": info["active_after_round0"]}
 
 
-def _pmc_traffic(kernel_prefix, workload, log2n, source_file, per_elem=None):
+_FPS = None
+
+
+def _fingerprints():
+    global _FPS
+    if _FPS is None:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_fingerprint as KF
+        _FPS = (KF, KF.kernel_fingerprints())
+    return _FPS
+
+
+def _pmc_traffic(kernel_prefix, workload, log2n, per_elem=None):
     """HBM bytes of a kernel from the committed rocprofv3 --pmc passes (profiles/*pmc_traffic*.json, made by
-    tools/pmc_summary.py).  A record names the kernel, the workload and the sha256 of the source file the kernel lives in: a
-    kernel that has changed since reports null instead of a stale figure."""
+    tools/pmc_summary.py).  A record names the kernel symbols it summed and the sha256 of their COMPILED code (machine code + kernel
+    descriptor, read out of libbwts_hip.so: tools/kernel_fingerprint.py): a kernel whose code has changed since reports null instead
+    of a stale figure, and an edit elsewhere in the kernel's source file does not retire the record."""
     try:
-        cur = hashlib.sha256(open(os.path.join(ROOT, "bijective-bwt_amd", "csrc", source_file), "rb").read()).hexdigest()
+        KF, fps = _fingerprints()
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             if not (name.endswith(".json") and "pmc_traffic" in name):
                 continue
@@ -189,7 +205,10 @@ def _pmc_traffic(kernel_prefix, workload, log2n, source_file, per_elem=None):
                 continue
             if per_elem is not None and pm.get("alg_bytes_per_element") != per_elem:
                 continue
-            if pm.get("source_sha256") != cur:       # (records without a hash cannot vouch for today's kernel either)
+            syms = pm.get("kernel_symbols")
+            if not syms or any(s not in fps for s in syms):       # (records without fingerprints cannot vouch for today's kernel)
+                continue
+            if KF.combined(fps, syms) != pm.get("code_sha256"):
                 continue
             return pm.get("hbm_bytes_per_launch", pm.get("hbm_bytes_per_forward")), name
     except Exception:
@@ -298,7 +317,14 @@ def _e2e(ctx, helper, d_in, d_out, n, workload):
             res["cli_wall_MBps"] = round(n / 1e6 / a["wall_s"], 1) if a["rc"] == 0 else None
             res["cli_inverse_wall_MBps"] = round(n / 1e6 / b["wall_s"], 1) if b["rc"] == 0 else None
             res["cli_wall_s"] = {"mk_bwts": round(a["wall_s"], 3), "unbwts": round(b["wall_s"], 3)}
-            res["cli_phases"] = [l for l in a["stderr"].splitlines() if " time " in l][-7:]
+            def phases(r):
+                lines = [l for l in r["stderr"].splitlines() if " time" in l][-8:]
+                for l in lines:
+                    if l.startswith("Process time") and "since launch" in l:        # what follows main(): exit handlers, the driver taking the memory back
+                        lines.append("After main() %.3f" % (r["wall_s"] - float(l.rsplit("since launch", 1)[1].split()[0])))
+                        break
+                return lines
+            res["cli_phases"] = {"mk_bwts": phases(a), "unbwts": phases(b)}
             if ok:
                 res["cli_output_equals_device_path"] = bool(np.array_equal(np.fromfile(out, dtype=np.uint8), ymem))
                 res["cli_roundtrip_exact"] = bool(np.array_equal(np.fromfile(rt, dtype=np.uint8), x))
@@ -445,7 +471,7 @@ def main(argv=None):
             20: "radix_scatter_packed_kernel<false,false,true> (8-bit LSD pass over packed streams: key-low 4 B + value 4 B + key-high|carried byte 2 B)",
             18: "radix_scatter_packed_kernel<false,false,false> (8-bit LSD pass over packed streams: key 4 B + value 4 B + carried byte 1 B)",
         }.get(per_elem, "radix_scatter2_kernel<512,16,4,true,false> (8-bit LSD pass, key 8 B + value 4 B + carried byte)")
-        traffic, traffic_src = _pmc_traffic(kernel_label, args.workload, args.log2n, "radix.hip", per_elem)
+        traffic, traffic_src = _pmc_traffic(kernel_label, args.workload, args.log2n, per_elem)
         size_label = "%d GiB" % (n >> 30) if n >= 1 << 30 and n % (1 << 30) == 0 else "%d MiB" % (n >> 20) if n >= 1 << 20 else "%d B" % n
         line = {
             "metric": "BWTS build MB/s on %s input (+ inverse MB/s); bit-exact round-trip" % size_label,
@@ -474,7 +500,7 @@ def main(argv=None):
         # second dominant kernel: the inverse's splitter walk -- bound by line fills, not bytes (one 128-byte fill per 4-byte LF read)
         wk = m["inv_main"].get("walk")
         if wk and wk.get("ms", 0) > 0:
-            wt, wsrc = _pmc_traffic("walk_record_kernel", args.workload, args.log2n, "inverse.hip")
+            wt, wsrc = _pmc_traffic("walk_record_kernel", args.workload, args.log2n)
             rw = _roofline("walk_record_kernel<3,16> (one LF chase per splitter, symbols recorded in 64-byte blocks; 6 n algorithmic bytes: "
                            "4 LF + 1 symbol + 1 output)", wk, wt, wsrc,
                            "HIP events on the engine's stream inside the timed inverse region (%d calls)" % args.inverse_steps)
@@ -507,7 +533,7 @@ def main(argv=None):
                 rk = t["main"].get("round")
                 if rk and rk.get("ms", 0) > 0:
                     # the text regime's dominant kernel: the group-local round over the chunked tied list (all launches of a forward)
-                    rt, rsrc = _pmc_traffic("chunk_round_kernel", "text", args.log2n, "chunk_rounds.h")
+                    rt, rsrc = _pmc_traffic("chunk_round_kernel", "text", args.log2n)
                     line["text"]["roofline"] = _roofline(
                         "chunk_round_kernel<true,3,true> + chunk_apply_moves_kernel (per list element and round: position + head in, three "
                         "successor ranks gathered, position + head out, rank updated = 32 algorithmic bytes)", rk, rt, rsrc,

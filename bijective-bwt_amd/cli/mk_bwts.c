@@ -25,6 +25,7 @@
 
 #include "bwts.h"
 #include "map_file.h"
+#include "cli_report.h"
 
 static void fail(const char *what, int code)
 {
@@ -32,13 +33,7 @@ static void fail(const char *what, int code)
 	exit(1);
 }
 
-static double now_s(void)
-{
-	struct timespec ts;
-	clock_gettime(CLOCK_MONOTONIC, &ts);
-	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
-}
-
+#define now_s cli_now_s
 static double write_s;
 
 /* The output is opened by the first piece that arrives (the reference computes first and opens afterwards, mk_bwts_sa.c:47-60):
@@ -117,6 +112,7 @@ int main(int argc, char **argv)
 	long len;
 	bwts_ctx *ctx;
 	struct out_file o;
+	bwts_timings t;
 	int rc;
 	const char *dev = getenv("BWTS_DEVICE");
 	const char *show_env = getenv("BWTS_TIMINGS");
@@ -126,7 +122,9 @@ int main(int argc, char **argv)
 	const int show = show_env && show_env[0] == '1';
 #endif
 	double t_start, t_wall;
+	struct cli_marks marks;
 
+	marks.main_start = now_s();
 	if (argc < 2) {
 		fprintf(stderr, "Usage: mk_bwts_sa <infile> [<outfile.bwts>]\n");
 #ifdef BWTS_AUTONAME
@@ -137,9 +135,11 @@ int main(int argc, char **argv)
 		exit(1);
 	}
 	map_in(text, len, argv[1]);
+	marks.mapped = now_s();
 
 	if ((rc = bwts_ctx_create(&ctx, dev ? atoi(dev) : 0)) != BWTS_OK)
 		fail("cannot open GPU context", rc);
+	marks.ctx_ready = now_s();
 	if (show)
 		bwts_set_timing(ctx, 2);
 	memset(&o, 0, sizeof o);
@@ -160,10 +160,11 @@ int main(int argc, char **argv)
 			fail("transform failed", rc);
 		exit(1);
 	}
-	t_wall = now_s() - t_start;
+	marks.done = now_s();
+	marks.write_s = write_s;
+	t_wall = marks.done - t_start;
 
 	if (show) {
-		bwts_timings t;
 		bwts_last_timings(ctx, &t);
 		/* the reference's five labels (mk_bwts_sa.c:50,124,168,190,62); seconds.  The engine has no separate ISA or
 		 * fix-up pass: "Compute ISA" is the regrouping / rank work of the doubling sort, "Fix sort order" the factor
@@ -178,13 +179,13 @@ int main(int argc, char **argv)
 		fprintf(stderr, "Transform (device) time %0.3f  H2D %0.3f  D2H+write %0.3f (fwrite %0.3f)  wall %0.3f\n", 1e-3 * t.total_ms,
 			1e-3 * t.h2d_ms, 1e-3 * t.d2h_ms, write_s, t_wall);
 		/* what a one-shot run pays outside kernels and copies */
-		fprintf(stderr, "Start-up time %0.3f  (HIP runtime + context %0.3f, code object load %0.3f)  allocation time %0.3f  (device in/out %0.3f, "
-			"pinned staging %0.3f, arenas %0.3f; %0.1f GiB on the device)\n",
-			1e-3 * (t.host_ms[BWTS_H_INIT] + t.host_ms[BWTS_H_MODULE]), 1e-3 * t.host_ms[BWTS_H_INIT], 1e-3 * t.host_ms[BWTS_H_MODULE],
-			1e-3 * (t.host_ms[BWTS_H_IO_ALLOC] + t.host_ms[BWTS_H_STAGING_ALLOC] + t.host_ms[BWTS_H_ARENA_ALLOC]),
-			1e-3 * t.host_ms[BWTS_H_IO_ALLOC], 1e-3 * t.host_ms[BWTS_H_STAGING_ALLOC], 1e-3 * t.host_ms[BWTS_H_ARENA_ALLOC],
-			(double)t.device_bytes / (double)(1ull << 30));
+		cli_report_host_costs(stderr, &t);
 	}
+	/* (the reference frees nothing and lets exit() do it, mk_bwts_sa.c:64; a library context is handed back properly, and the
+	 * time that takes is reported) */
 	bwts_ctx_destroy(ctx);
+	marks.destroyed = now_s();
+	if (show)
+		cli_report_process(stderr, &marks);
 	return 0;
 }

@@ -18,6 +18,9 @@
 
 #include "bwts.h"
 #include "map_file.h"
+#include "cli_report.h"
+
+static double write_s;
 
 /* The output is opened by the first piece that arrives (the reference computes first and calls write_out() afterwards,
  * unbwts.c:62-89): by then the whole input has been read, so `unbwts f f` works, and a failing transform leaves nothing behind. */
@@ -61,12 +64,17 @@ static void open_output(struct out_file *o)
 static int write_piece(void *user, const uint8_t *data, uint64_t len)
 {
 	struct out_file *o = (struct out_file *)user;
+	double t0;
+	size_t done;
 
 	if (!o->fp && !o->failed)
 		open_output(o);
 	if (o->failed)
 		return 1;
-	if (fwrite(data, 1, (size_t)len, o->fp) != (size_t)len) {
+	t0 = cli_now_s();
+	done = fwrite(data, 1, (size_t)len, o->fp);
+	write_s += cli_now_s() - t0;
+	if (done != (size_t)len) {
 		perror("write");
 		o->failed = 1;
 		return 1;
@@ -82,19 +90,29 @@ int main(int argc, char **argv)
 	struct out_file o;
 	int rc;
 	const char *dev = getenv("BWTS_DEVICE");
-	const char *show = getenv("BWTS_TIMINGS");
+	const char *show_env = getenv("BWTS_TIMINGS");
+#ifdef SHOW_TIMINGS
+	const int show = 1;
+#else
+	const int show = show_env && show_env[0] == '1';
+#endif
+	struct cli_marks marks;
+	bwts_timings t;
 
+	marks.main_start = cli_now_s();
 	if (argc < 2) {
 		fprintf(stderr, "Usage: unbwts <infile.bwts> [<outfile>]\n");
 		fprintf(stderr, "If output file name is unspecified, a name is generated\n");
 		exit(1);
 	}
 	map_in(bwts, len, argv[1]);
+	marks.mapped = cli_now_s();
 
 	if ((rc = bwts_ctx_create(&ctx, dev ? atoi(dev) : 0)) != BWTS_OK) {
 		fprintf(stderr, "unbwts: %s\n", bwts_strerror(rc));
 		exit(1);
 	}
+	marks.ctx_ready = cli_now_s();
 	memset(&o, 0, sizeof o);
 	o.explicit_name = argc < 3 ? NULL : argv[2];
 	o.in_name = argv[1];
@@ -110,12 +128,18 @@ int main(int argc, char **argv)
 			fprintf(stderr, "unbwts: %s\n", bwts_strerror(rc));
 		exit(1);
 	}
-	if (show && show[0] == '1') {
-		bwts_timings t;
+	marks.done = cli_now_s();
+	marks.write_s = write_s;
+	/* The reference's unbwts has no timers; these are the forward program's extra lines, same format. */
+	if (show) {
 		bwts_last_timings(ctx, &t);
-		fprintf(stderr, "Transform (device) time %0.3f  H2D %0.3f  D2H+write %0.3f\n", 1e-3 * t.total_ms, 1e-3 * t.h2d_ms,
-			1e-3 * t.d2h_ms);
+		fprintf(stderr, "Transform (device) time %0.3f  H2D %0.3f  D2H+write %0.3f (fwrite %0.3f)  wall %0.3f\n", 1e-3 * t.total_ms,
+			1e-3 * t.h2d_ms, 1e-3 * t.d2h_ms, write_s, marks.done - marks.ctx_ready);
+		cli_report_host_costs(stderr, &t);
 	}
 	bwts_ctx_destroy(ctx);
+	marks.destroyed = cli_now_s();
+	if (show)
+		cli_report_process(stderr, &marks);
 	return 0;
 }

@@ -7,6 +7,10 @@
 #include <time.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
 
 double wall_ms(void)
 {
@@ -156,12 +160,34 @@ void bwts_stage_mark(bwts_ctx *ctx, const char *name)
     fflush(stderr);
 }
 
+// The arena changes hands on the thread that owns the context, and only with the context's stream drained: nothing that was
+// enqueued can still use the block that is given up.
+int arena_release(bwts_ctx *ctx)
+{
+    if (!ctx->arena) return BWTS_OK;
+    HIPC(hipStreamSynchronize(ctx->stream));
+    HIPC(ctx_free(ctx, ctx->arena));
+    ctx->arena = nullptr;
+    ctx->arena_cap = 0;
+    ctx->arena_off = 0;
+    return BWTS_OK;
+}
+
+void arena_install(bwts_ctx *ctx, void *block, size_t bytes, double alloc_ms)
+{
+    trace_alloc(ctx, "device +", "arena", block, bytes);
+    ctx->arena = (char *)block;
+    ctx->arena_cap = bytes;
+    ctx->arena_off = 0;
+    ctx->host_ms[BWTS_H_ARENA_ALLOC] += alloc_ms;
+}
+
 int arena_reserve(bwts_ctx *ctx, size_t bytes)
 {
     bytes = align_up(bytes, 1 << 20);
     if (bytes > ctx->arena_cap) {
         const double t0 = wall_ms();
-        if (ctx->arena) { HIPC(ctx_free(ctx, ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
+        BWTS_TRY(arena_release(ctx));
         void *p = nullptr;
         if (ctx_malloc(ctx, &p, bytes, "arena") != hipSuccess) { (void)hipGetLastError(); return BWTS_E_NOMEM; }
         ctx->arena = (char *)p;
@@ -341,7 +367,7 @@ extern "C" int bwts_ctx_release_memory(bwts_ctx *ctx)
     if (!ctx) return BWTS_E_ARG;
     HIPC(hipSetDevice(ctx->device));
     HIPC(hipStreamSynchronize(ctx->stream));
-    if (ctx->arena) { HIPC(ctx_free(ctx, ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; ctx->arena_off = 0; }
+    BWTS_TRY(arena_release(ctx));
     for (int i = 0; i < BWTS_AUX_SLOTS; i++)
         if (ctx->aux[i]) { HIPC(ctx_free(ctx, ctx->aux[i])); ctx->aux[i] = nullptr; ctx->aux_cap[i] = 0; }
     for (char *b : ctx->tied_blk) HIPC(hipFree(b));
@@ -414,11 +440,20 @@ extern "C" int bwts_inverse_device(bwts_ctx *ctx, const void *d_in, uint64_t n, 
 void CopyPool::part(int i)
 {
     if (touching) {                   // workers 1 .. parts-1 share the buffer; the caller takes no part
+        // MADV_POPULATE_WRITE maps the pages writable WITHOUT changing what they hold (a store of zeros, the first form, clobbered
+        // the caller's buffer although the call could still fail, and -- in a batch -- an input that the output aliases).  Where the
+        // kernel refuses it (before Linux 5.14, or a mapping it cannot populate) nothing is pre-faulted: the copy out pays the faults.
         const int nw = parts - 1;
-        const size_t per = ((len / (size_t)nw) + 4095) & ~(size_t)4095;
-        const size_t lo = per * (size_t)(i - 1) < len ? per * (size_t)(i - 1) : len;
-        const size_t hi = i == nw ? len : (lo + per < len ? lo + per : len);
-        for (size_t o = lo; o < hi; o += 4096) ((volatile char *)dst)[o] = 0;
+        const uintptr_t b = ((uintptr_t)dst + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)dst + len) & ~(uintptr_t)4095;
+        if (e <= b) return;
+        const size_t pages = (e - b) >> 12, per = (pages + (size_t)nw - 1) / (size_t)nw;
+        const size_t lo = per * (size_t)(i - 1) < pages ? per * (size_t)(i - 1) : pages;
+        const size_t hi = lo + per < pages ? lo + per : pages;
+        // (in pieces of 32 MiB: a worker that is told to stop gives up soon)
+        for (size_t o = lo; o < hi && !touch_failed.load(std::memory_order_relaxed); o += 8192) {
+            const size_t cnt = hi - o < 8192 ? hi - o : 8192;
+            if (madvise((void *)(b + (o << 12)), cnt << 12, MADV_POPULATE_WRITE) != 0) touch_failed.store(true, std::memory_order_relaxed);
+        }
         return;
     }
     // page-aligned cuts: two workers never fault on the same page of a fresh destination
@@ -473,6 +508,7 @@ void CopyPool::touch_async(void *d, size_t n)
         std::lock_guard<std::mutex> lk(mu);
         dst = (char *)d; src = nullptr; len = n;
         touching = true;
+        touch_failed.store(false, std::memory_order_relaxed);
         pending = parts - 1;
         generation++;
     }
@@ -649,7 +685,7 @@ static int ensure_io(bwts_ctx *ctx, u64 n, bool pairs)
     for (int i = 0; i < 4; i++) {
         if (!pairs && (i & 1)) continue;
         if (ctx->d_io_cap[i] >= n) continue;
-        if (ctx->d_io[i]) { HIPC(ctx_free(ctx, ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
+        if (ctx->d_io[i]) { HIPC(hipStreamSynchronize(ctx->stream)); HIPC(ctx_free(ctx, ctx->d_io[i])); ctx->d_io[i] = nullptr; ctx->d_io_cap[i] = 0; }
         void *p = nullptr;
         const size_t cap = align_up((size_t)n, 1 << 20);
         static const char *const io_names[4] = {"device input 0", "device input 1", "device output 0", "device output 1"};
@@ -674,22 +710,44 @@ static int run_host(bwts_ctx *ctx, device_impl_fn fn, const uint8_t *in, uint64_
     trace_alloc(ctx, "call    ", fn == forward_device_impl ? "forward: in" : "inverse: in", in, n);
     if (out) trace_alloc(ctx, "call    ", "out", out, n);
     Stager &sg = ctx->stg[0];
-    // a context's first call allocates its arena, which can cost as long as the whole input copy (the driver clears what it hands
-    // out): a helper thread does it while this one stages the input
+    // A context's first call allocates its arena, which can cost as long as the whole input copy where the driver clears what it
+    // hands out: a helper thread does the hipMalloc -- and nothing else -- while this thread stages the input.  Rules (DESIGN.md
+    // section 9: a GPU memory fault followed four arena re-reservations that an earlier form did wholly on the helper):
+    //  * only a context that holds NO arena takes the helper (the one-shot CLI it was built for); a context that has to give up a
+    //    smaller arena first does everything on this thread -- arena_release() drains the stream, then frees -- before staging starts;
+    //  * the helper touches no context state: it allocates into a local, this thread installs the block after join().
+    // BWTS_RESERVE_HELPER=1 (a test switch) sends EVERY growth through the helper, after the release on this thread.
     const size_t want = arena_hint(fn, n);
     std::thread reserve;
-    int reserve_rc = BWTS_OK;
-    // (only where it can pay: a block of a few MiB is allocated by the transform itself, on this thread, as on the _device path)
-    if (want > ctx->arena_cap && want - ctx->arena_cap >= ((size_t)256 << 20))
-        reserve = std::thread([ctx, want, &reserve_rc] { if (hipSetDevice(ctx->device) == hipSuccess) reserve_rc = arena_reserve(ctx, want); });
+    void *fresh = nullptr;
+    double reserve_ms = 0;
+    if (want > ctx->arena_cap) {
+        const char *force = bwts_knob(ctx, "BWTS_RESERVE_HELPER");
+        const bool helper = !ctx->guard && (force ? force[0] == '1' : (ctx->arena == nullptr && want >= ((size_t)256 << 20)));
+        if (helper) {
+            BWTS_TRY(arena_release(ctx));
+            const size_t bytes = align_up(want, 1 << 20);
+            const int device = ctx->device;
+            reserve = std::thread([device, bytes, &fresh, &reserve_ms] {
+                const double t0 = wall_ms();
+                void *p = nullptr;
+                if (hipSetDevice(device) == hipSuccess && hipMalloc(&p, bytes) == hipSuccess) fresh = p;
+                else (void)hipGetLastError();
+                reserve_ms = wall_ms() - t0;
+            });
+        }
+    }
     double t0 = wall_ms();
     const int h2d_rc = staged_h2d(ctx, sg, ctx->d_io[0], in, n);
-    if (reserve.joinable()) reserve.join();
+    if (reserve.joinable()) {
+        reserve.join();
+        if (fresh) arena_install(ctx, fresh, align_up(want, 1 << 20), reserve_ms);     // (no block: the transform's own reservation reports it)
+    }
     BWTS_TRY(h2d_rc);
     STAGE("host path: input on the device");
-    if (reserve_rc != BWTS_OK && reserve_rc != BWTS_E_NOMEM) return reserve_rc;       // (out of memory: the transform's own reservation reports it)
     const double h2d = wall_ms() - t0;
-    // the caller's output buffer is usually fresh: its page faults are taken by the copy workers during the transform
+    // the caller's output buffer is usually fresh: its page faults are taken by the copy workers during the transform (contents
+    // untouched: a call that fails leaves the buffer as it was, like the reference, which writes only after success: mk_bwts_sa.c:52-60)
     const bool touch = !sink && !is_pinned_block(ctx, out, n) && ensure_staging(ctx, sg) == BWTS_OK;
     if (touch) sg.pool->touch_async(out, n);
     const int rcd = run_device(ctx, fn, ctx->d_io[0], n, ctx->d_io[2]);
@@ -726,6 +784,12 @@ static int run_batch(bwts_ctx *ctx, device_impl_fn fn, int count, const uint8_t 
         if (ns[k] > nmax) nmax = ns[k];
     }
     if (count == 0) return BWTS_OK;
+    // An item's output may lie on its OWN input (in place, like `mk_bwts f f`: the input is on the device before a byte comes back) or on
+    // an earlier item's.  It may not touch a LATER item's input: that item may not have been staged yet when this one is drained (single
+    // calls in sequence would hand the later call the overwritten bytes; here it would be a race) -- refused.
+    for (int k = 0; k < count; k++)
+        for (int j = k + 1; j < count; j++)
+            if (outs[k] < ins[j] + ns[j] && ins[j] < outs[k] + ns[k]) return BWTS_E_ARG;
     HIPC(hipSetDevice(ctx->device));
     BWTS_TRY(ensure_io(ctx, nmax, true));
     BWTS_TRY(ensure_staging(ctx, ctx->stg[1]));
@@ -754,7 +818,8 @@ static int run_batch(bwts_ctx *ctx, device_impl_fn fn, int count, const uint8_t 
     std::thread drainer([&] {
         if (hipSetDevice(ctx->device) != hipSuccess) { fail(BWTS_E_HIP); return; }
         for (int k = 0; k < count; k++) {
-            // the caller's buffer is usually fresh: fault its pages in while the item is still being transformed
+            // the caller's buffer is usually fresh: fault its pages in while the item is still being transformed (the pages' contents
+            // stay as they are -- CopyPool::part -- so an output that lies on an input not yet staged does it no harm)
             const bool touch = !is_pinned_block(ctx, outs[k], ns[k]);
             if (touch) ctx->stg[2].pool->touch_async(outs[k], ns[k]);
             {

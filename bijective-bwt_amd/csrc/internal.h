@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <atomic>
 
 #include "../../include/bwts.h"
 
@@ -36,11 +37,13 @@ struct CopyPool {
     const char *src = nullptr;
     size_t len = 0;
     int parts = 1;
-    bool touching = false;  // the current job writes one byte per page of dst instead of copying
+    bool touching = false;  // the current job pre-faults the pages of dst (madvise, contents untouched) instead of copying
+    std::atomic<bool> touch_failed{false};
     void start(int threads);
     void copy(void *dst, const void *src, size_t len);      // returns when all parts are done
-    // The workers alone fault in the pages of a fresh buffer (one zero byte per 4 KiB) while the caller goes on: the
-    // first-touch faults of a caller's output buffer are paid while the GPU transforms.  wait() before the next job.
+    // The workers alone fault in the pages of a fresh buffer (MADV_POPULATE_WRITE: mapped writable, contents as they were) while
+    // the caller goes on: the first-touch faults of a caller's output buffer are paid while the GPU transforms.  wait() before the
+    // next job.
     void touch_async(void *dst, size_t len);
     void wait();
     void shutdown();
@@ -147,6 +150,8 @@ double wall_ms(void);
 
 // ---- arena -------------------------------------------------------------------
 int  arena_reserve(bwts_ctx *ctx, size_t bytes);        // (re)allocates when too small; resets
+int  arena_release(bwts_ctx *ctx);                      // drains the context's stream, then gives the arena up (calling thread only)
+void arena_install(bwts_ctx *ctx, void *block, size_t bytes, double alloc_ms);
 void arena_reset(bwts_ctx *ctx);
 void *arena_alloc(bwts_ctx *ctx, size_t bytes);         // NULL when exhausted
 template <typename T> static inline T *arena_array(bwts_ctx *ctx, u64 count)

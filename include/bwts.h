@@ -127,7 +127,8 @@ int bwts_inverse_sink(bwts_ctx *ctx, const uint8_t *in, uint64_t n, bwts_sink_fn
 /* Several independent inputs, one after another on this context (what a GPU does in a batched job: BASELINE config 5 puts one such
  * stream of files on every GPU), with the copies overlapped with the transforms: while item k is transformed, item k + 1 is on its
  * way to the device and item k - 1 on its way back.  ins[k] / outs[k]: caller-owned host memory of ns[k] bytes each (unpinned is
- * fine); the bytes are those of count single calls.  Stops at the first error.  Afterwards bwts_last_timings() describes the
+ * fine); the bytes are those of count single calls.  outs[k] may lie on ins[k] (in place) or on an earlier item's input; an output that
+ * overlaps a LATER item's input is refused with BWTS_E_ARG (that input may not have left the host yet).  Stops at the first error.  Afterwards bwts_last_timings() describes the
  * last item's transform, with d2h_ms = wall time of the whole batch. */
 int bwts_forward_batch(bwts_ctx *ctx, int count, const uint8_t *const *ins, const uint64_t *ns, uint8_t *const *outs);
 int bwts_inverse_batch(bwts_ctx *ctx, int count, const uint8_t *const *ins, const uint64_t *ns, uint8_t *const *outs);

@@ -661,6 +661,64 @@ def test_batch_equals_single_calls(ctx, pkg):
     assert pkg.lib().bwts_forward_batch(ctx._h, 2, ok_in, ns0, bad_out) == -1
 
 
+def test_arena_regrown_on_a_reused_context(pkg):
+    """a context that already holds an arena meets a larger input through the host-buffer entry point.  The old
+    block is given up on the calling thread with the stream drained, before the input is staged; growth of 256 MiB and more used
+    to be done on a helper thread beside the copies.  Fresh context (its first reservation is the one case that still overlaps the
+    hipMalloc with the input copy), small call, then 12 MiB (arena + 300 MiB), then small again."""
+    small = O.generate("uniform256", 70001, 5)
+    big = O.generate("zipf", 12 << 20, 6)
+    with pkg.Context(0) as c:
+        assert np.array_equal(c.forward(small), O.forward(small))
+        held = c.timings().device_bytes
+        y = c.forward(big)
+        assert c.timings().device_bytes >= held + (256 << 20)
+        assert np.array_equal(y, O.forward(big))
+        assert np.array_equal(c.inverse(y), big)
+        assert np.array_equal(c.forward(small), O.forward(small))
+    with pkg.Context(0) as c:                                       # first call of a context: the helper's case
+        assert np.array_equal(c.forward(big), y)
+
+
+def test_failed_call_leaves_the_output_buffer_alone(ctx, pkg):
+    """The output pages are pre-faulted while the GPU works without changing their contents (MADV_POPULATE_WRITE), so a call that
+    fails after that point has not written to the caller's buffer (the reference writes only after success: mk_bwts_sa.c:52-60).
+    Forced here with a sink-less call whose transform is refused: length 0 is refused before anything; a real late failure is not
+    constructible on demand, so the property is checked where it is observable -- in place, output == input buffer, >= 4 MiB:
+    a pre-fault that wrote zeros would corrupt every 4096th input byte before staging had read it."""
+    x = O.generate("text", (6 << 20) + 3, 9)
+    want = ctx.forward(x)
+    buf = x.copy()
+    ctx.forward_into(buf, buf)
+    assert np.array_equal(buf, want)
+    ctx.inverse_into(buf, buf)
+    assert np.array_equal(buf, x)
+
+
+def test_batch_in_place_and_overlap_rules(ctx, pkg):
+    """Batch items may be transformed in place (outs[k] == ins[k], items beyond the 4 MiB pre-fault threshold); an output that
+    overlaps a LATER item's input is refused (bwts.h)."""
+    import ctypes
+    xs = [O.generate("zipf", (5 << 20) + 7, 61), O.generate("text", 6 << 20, 62), O.generate("uniform256", (4 << 20) + 4096, 63)]
+    want = [ctx.forward(x) for x in xs]
+    bufs = [x.copy() for x in xs]
+    k = len(bufs)
+    ptrs = (ctypes.c_void_p * k)(*[b.ctypes.data for b in bufs])
+    ns = (ctypes.c_uint64 * k)(*[b.size for b in bufs])
+    assert pkg.lib().bwts_forward_batch(ctx._h, k, ptrs, ns, ptrs) == 0
+    for b, w in zip(bufs, want):
+        assert np.array_equal(b, w)
+    assert pkg.lib().bwts_inverse_batch(ctx._h, k, ptrs, ns, ptrs) == 0
+    for b, x in zip(bufs, xs):
+        assert np.array_equal(b, x)
+    # output 0 on input 1 (a later item): refused, nothing changed
+    outs = (ctypes.c_void_p * k)(bufs[1].ctypes.data, bufs[0].ctypes.data, bufs[2].ctypes.data)
+    ns2 = (ctypes.c_uint64 * k)(min(bufs[0].size, bufs[1].size), min(bufs[0].size, bufs[1].size), bufs[2].size)
+    assert pkg.lib().bwts_forward_batch(ctx._h, k, ptrs, ns2, outs) == -1
+    for b, x in zip(bufs, xs):
+        assert np.array_equal(b, x)
+
+
 def test_sink_error_aborts(ctx, pkg):
     import ctypes
     x = O.generate("zipf", 100000, 2)
@@ -1061,6 +1119,7 @@ def test_smoke_entry():
     {"BWTS_SPLIT_LOG2": "0"},                         # inverse: every element a splitter (plain pointer jumping)
     {"BWTS_POISON": "1"},                             # every arena / side block filled with 0xA5 before use: nothing may read what nothing wrote
     {"BWTS_POISON": "1", "BWTS_DENSE": "tiles"},
+    {"BWTS_RESERVE_HELPER": "1"},                     # host path: EVERY arena growth through the helper thread (release on the caller with the stream drained, hipMalloc alone on the helper: DESIGN.md section 9)
 ], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_alternate_paths(env):
     # (-s: the child must not capture its tests' stderr -- what the HIP runtime says when it aborts the process would stay in the capture file)

@@ -10,12 +10,14 @@ reported in KB, and FETCH_SIZE counts half of the coalesced read bytes on gfx950
 """
 import collections
 import csv
-import hashlib
 import json
 import os
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_fingerprint as KF
 CORRECTION = "gfx950: FETCH_SIZE reports 1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM section) -> x2; WRITE_SIZE as is; units KB"
 # (record name, kernel-name prefixes summed together, source file, algorithmic bytes per element, per what)
 ROOFLINE = [
@@ -32,8 +34,12 @@ def load(path):
     return acc
 
 
-def sha(source):
-    return hashlib.sha256(open(os.path.join(ROOT, "bijective-bwt_amd", "csrc", source), "rb").read()).hexdigest()
+def demangled_map(fps):
+    """{demangled kernel name (as rocprofv3 prints it): mangled symbol} for the library's kernels (llvm-cxxfilt of this image)."""
+    syms = sorted(fps)
+    tool = "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    out = subprocess.run([tool], input="\n".join(syms) + "\n", stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+    return dict(zip(out, syms))
 
 
 def main():
@@ -47,12 +53,24 @@ def main():
             allk.setdefault(k[:120], {})[name] = {"launches_total": len(rows), "largest_launches": len(big), "mean_KB_largest": sum(big) / len(big),
                                                   "sum_KB": sum(v for _, v in rows)}
     json.dump(allk, open(os.path.join(out_dir, "%s_pmc_fetch_write_all_kernels_%s_2p%d.json" % (tag, workload, log2n)), "w"), indent=1)
+    fps = KF.kernel_fingerprints()
+    dem = demangled_map(fps)
     for rec, prefixes, source, per_elem, per in ROOFLINE:
         keys = [k for k in allk if any(k.startswith("void " + p) or k.startswith(p) for p in prefixes)]
         if not keys:
             continue
+        # the record vouches for exactly the kernels whose launches it sums: their compiled code, by fingerprint
+        symbols = {}
+        for k in keys:
+            hit = [m for d, m in dem.items() if d[:120] == k or d.startswith(k)]
+            if len(hit) != 1:
+                print("warning: %s: %d library kernels match %r" % (rec, len(hit), k), file=sys.stderr)
+            for m in hit:
+                symbols[m] = fps[m]
         out = {"kernel": prefixes[0] if len(prefixes) == 1 else " + ".join(prefixes), "alg_bytes_per_element": per_elem,
-               "workload": "%s(2^%d, seed 1)" % (workload, log2n), "log2n": log2n, "source_file": "csrc/" + source, "source_sha256": sha(source),
+               "workload": "%s(2^%d, seed 1)" % (workload, log2n), "log2n": log2n, "source_file": "csrc/" + source,
+               "kernel_symbols": symbols, "code_sha256": KF.combined(fps, symbols),
+               "keyed_on": "sha256 over each kernel's machine code + kernel descriptor in libbwts_hip.so (tools/kernel_fingerprint.py)",
                "correction": CORRECTION, "collected": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes"}
         if per == "launch":
             f = sum(allk[k]["FETCH_SIZE"]["mean_KB_largest"] for k in keys)

@@ -19,12 +19,15 @@ try:
     pk = os.path.join(ROOT, "bijective-bwt_amd")
     for r in range(runs):
         for prog, a, b in (("mk_bwts", src, out), ("unbwts", out, back)):
+            env["BWTS_T0_NS"] = str(time.clock_gettime_ns(time.CLOCK_MONOTONIC))      # the CLI reports what passed before its main()
             t0 = time.perf_counter()
             p = subprocess.run([os.path.join(pk, prog), a, b], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             wall = time.perf_counter() - t0
             print("run %d %s: rc %d wall %.3f s = %.0f MB/s" % (r, prog, p.returncode, wall, n / 1e6 / wall))
             for l in p.stderr.decode().splitlines():
                 if "time" in l: print("    " + l)
+                if l.startswith("Process time") and "since launch" in l:
+                    print("    after main() returned (exit handlers, device memory handed back by the driver): %.3f s" % (wall - float(l.rsplit("since launch", 1)[1].split()[0])))
             time.sleep(1.0)
     print("round trip exact:", bool(np.array_equal(np.fromfile(back, dtype=np.uint8), x)))
 finally:
