@@ -8,8 +8,8 @@
 //     CH_TILE slots cut at group starts, orders every group in LDS exactly like dense_round_kernel, and writes the members that
 //     stay tied back IN PLACE, compacted to the front of the chunk (the write cursor never passes the read cursor);
 //   * the rank array is only read by the round kernel: the new ranks of the elements whose rank changed go to a per-chunk move
-//     list, which chunk_apply_moves_kernel applies when the round's gathers are all done (a round's keys must come from one version
-//     of the ranks);
+//     list of records, which chunk_apply_records_kernel applies when the round's gathers are all done (a round's keys must come from
+//     one version of the ranks);
 //   * the grid is one workgroup per chunk in every round and the sizes live on the device, so the host has nothing to read back
 //     between rounds except "is anything left / did anything split": once no larger group is left it enqueues two rounds per sync.
 // The one-off order by smallest position covers the groups of up to CH_CAP members; the larger ones are put behind them, unordered.
@@ -42,9 +42,31 @@
 #define CH_GROUP_MAX CH_TILE             // largest group a chunk may hold (a tile of its own in a WIDE chunk)
 #define CH_MIN_LIST 65536ull            // shorter lists keep the tile form (dense_rounds)
 #define CH_SLOTS   4                    // result slots of rounds in flight
-#define CH_SLOT_WORDS 8
+#define CH_SLOT_WORDS 16
 #define SM_CHSLOT  (SM_DGCNT + 16)      // CH_SLOTS x CH_SLOT_WORDS words inside the dense rounds' counter block
-enum { CHS_SPLIT = 0, CHS_ERR = 1, CHS_TOTAL = 2, CHS_EXIT = 3, CHS_STAY = 4 };
+enum { CHS_SPLIT = 0, CHS_ERR = 1, CHS_TOTAL = 2, CHS_EXIT = 3, CHS_STAY = 4, CHS_PARKED = 8 };
+
+// ---- PARKED CHAINS (round 4) ---------------------------------------------------------------------------------------------------
+// Inside a repeated stretch the copies tie position by position: the tied group A = {x_1 .. x_s} is followed, one position on, by the
+// tied group A' = {x_1 + 1 .. x_s + 1}, and so on to the end of the stretch.  All x_i share their first symbol, so the order of A's
+// members IS the order of A''s: refining A every round, as the rounds before did (most of a text's tied list sits in such stretches
+// for a dozen rounds), repeats what A''s refinement already says.  So: a group whose members' cyclic successors (distance 1) form
+// exactly one other tied group of the same size -- all successor ranks equal, that group's size equal to its own, no member at its
+// factor's last position -- is not refined.  It PARKS: its members leave the list for good and set a flag in position space.  What a
+// round does to a member q of a group that is refined (new rank = old + delta; alone now; new group size) is INDUCED onto the
+// positions q - 1, q - 2, ... while they carry the flag: the chain behind q, which by construction holds the corresponding members of
+// the groups parked behind q's.  Every chain ends in a group that is refined (the one holding a factor's last position never parks),
+// so nothing waits for ever, and a round in which no refined group splits still proves what it proved before: equal infinite words.
+// Sound because the partition only ever gets FINER than the classic rounds' (a parked group receives its leader's refinement, which
+// looks one symbol further per chain link), and doubling tolerates ranks that are finer than h-consistent.
+// pinfo[x] (one byte per text position): low 7 bits = size of x's group while x is tied (127: 127 or more; 0: not tied, or not known:
+// members of groups that only the WIDE kernel / the big list have handled so far), bit 7 = parked.  Like rank[], pinfo is only READ by
+// the round kernels (except for the parked flag, which no reader of the sizes looks at); the record pass applies the changes.
+// A round's record of a member (what chunk_apply_moves_kernel's (new rank, position) pairs were): position, delta, new size, alone.
+#define CH_PARK_MAX 126u                 // largest group that may park (its size must be told apart from "127 or more")
+#define CH_REC(pos, delta, size7, alone, eqb) ((u64)(pos) | ((u64)(delta) << 32) | ((u64)(size7) << 44) | ((u64)((alone) ? 1u : 0u) << 51) | ((u64)(eqb) << 53))
+#define CH_REC_SELF (1ull << 52)         // (the final lay-out of equal words) the member's own byte and suffix-array slot are written by the record pass too
+#define CH_SHORT_CHAIN 8                 // chain positions the record's own lane walks before it hands the chain to a wave (0: every chain to a wave -- measured: 58 against 38 ms of record passes per text(2^30) forward)
 static_assert(CH_CAP * 4 <= CH_TILE, "a tile must hold several whole groups");
 static_assert(16 + CH_SLOTS * CH_SLOT_WORDS <= DG_CNT_BIG + DG_CNT_SPREAD, "result slots live in the dense rounds' counter block");
 
@@ -89,13 +111,17 @@ __device__ __forceinline__ void chunk_bitonic_sort(u32 *key, u64 *key23, u32 *pa
 // modulo the length from one 16-byte LDS read (FSL: at most CH_FS factors -- natural data has a dozen or two; inputs with more
 // take the instantiation with the general 64-bit arithmetic); and a slot's group extent comes from the wave's own __ballot word
 // (which is exactly the 64 slots of its lanes) plus two per-word neighbour values, not from a bit search over LDS per lane.
-template <bool CYCLIC, int NKEYS, bool FSL /* cyclic, at most CH_FS factors: their data sits in LDS */, bool WIDE /* the chunks flagged in cwide, and only those */>
+template <bool CYCLIC, int NKEYS, bool FSL /* cyclic, at most CH_FS factors: their data sits in LDS */, bool WIDE /* the chunks flagged in cwide, and only those */,
+          bool PARK = false /* parked chains (needs CYCLIC and FSL): its own instantiation, so that the default one pays no register for it */>
 __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_round_kernel(u32 *idx, u32 *head, const u32 *__restrict__ cstart, u32 *__restrict__ ccount,
                                                                  u8 *__restrict__ cwide, u64 *__restrict__ mv, u32 *__restrict__ mvcount,
                                                                  const u32 *__restrict__ rank, u64 n, u64 h,
                                                                  const u32 *__restrict__ fstart, u64 k,
-                                                                 PrevSym prev, u8 *__restrict__ out, unsigned long long *__restrict__ result)
+                                                                 PrevSym prev, u8 *__restrict__ out, unsigned long long *__restrict__ result,
+                                                                 u8 *pinfo /* null: no parked chains */, u32 park_on /* groups may park in this round */)
 {
+    static_assert(!PARK || (CYCLIC && FSL), "parked chains: cyclic sort with the factors in LDS");
+    const bool park = PARK && !WIDE && park_on != 0;
     __shared__ u32 hd[CH_TILE];              // group heads of the tile
     __shared__ u32 key[CH_TILE];             // successor ranks
     __shared__ u64 key23[NKEYS == 3 ? CH_TILE : 1];
@@ -106,14 +132,14 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
     __shared__ u32 fhm3[FSL ? CH_FS : 1];               // ... and 3h
     __shared__ u32 fdir[FSL ? 256 : 1];                 // factor that holds position b << dsh: a lookup starts there
     __shared__ u32 hd2[WIDE ? CH_TILE : 1];  // (WIDE) the heads, while hd carries the sort's payload
-    __shared__ u32 s_surv, s_nmv, s_split, s_err, s_wide;
+    __shared__ u32 s_surv, s_nmv, s_split, s_err, s_wide, s_npark;
     const int tid0 = threadIdx.x;
     const u32 c = blockIdx.x;
     if ((cwide[c] != 0) != WIDE) return;
     const u64 base = (u64)(u32)__builtin_amdgcn_readfirstlane((int)cstart[c]);
     const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)ccount[c]);
     if (cnt == 0) { if (tid0 == 0) mvcount[c] = 0; return; }
-    if (tid0 == 0) { s_nmv = 0; s_split = 0; s_err = 0; s_wide = 0; }
+    if (tid0 == 0) { s_nmv = 0; s_split = 0; s_err = 0; s_wide = 0; s_npark = 0; }
     // the step, wave-uniform.  Cyclic with the factors in LDS: per factor the step(s) reduced modulo its length (a division only
     // for factors shorter than the step: the short ones at the text's end), and a 256-entry directory over the positions' top bits
     // so that finding a position's factor is one table read and (nearly always) one comparison.  Suffixes: p + j h < n <=> p < nhj.
@@ -170,9 +196,11 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
         u32 my_key[CH_ITEMS];
         u64 my_key23[NKEYS == 3 ? CH_ITEMS : 1];
         u32 ppos[CH_ITEMS];                      // position of the previous symbol, T[cprev(p)] (mk_bwts_sa.c:172-188), while the factor is at hand
+        u32 s1r[PARK ? CH_ITEMS : 1], s1i[PARK ? CH_ITEMS : 1];        // parking: rank and pinfo byte of the cyclic successor at distance 1 (s1i = 0x100: p ends its factor)
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++) {
             my_key[j] = 0; ppos[j] = 0;
+            if (PARK) { s1r[PARK ? j : 0] = 0; s1i[PARK ? j : 0] = 0x100u; }
             if (NKEYS == 3) my_key23[NKEYS == 3 ? j : 0] = 0;
             if ((u32)j * CH_THREADS + tid >= len) continue;
             const u32 p = myp[j];
@@ -189,6 +217,7 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
                     u32 o = dd + ft.z;
                     o = (o < dd || o >= L) ? o - L : o;
                     q1 = s0 + o;
+                    if (PARK && park && dd + 1u != L) { s1r[PARK ? j : 0] = rank[p + 1u]; s1i[PARK ? j : 0] = (u32)pinfo[p + 1u]; }
                     if (NKEYS == 3) {
                         u32 o2 = dd + ft.w, o3 = dd + fhm3[f];
                         o2 = (o2 < dd || o2 >= L) ? o2 - L : o2;
@@ -225,8 +254,8 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
         __syncthreads();
         const u64 le = lane == 63 ? ~0ull : (2ull << lane) - 1ull;       // slots of the word at or below mine
         u32 plen = len;
-        u32 dst[CH_ITEMS], newhead[CH_ITEMS];
-        bool alone[CH_ITEMS], moved[CH_ITEMS], act[CH_ITEMS];
+        u32 dst[CH_ITEMS], newhead[CH_ITEMS], dl[CH_ITEMS], nsz[CH_ITEMS], eqb[CH_ITEMS];      // dl: new rank - old rank; nsz: size of the new group (0 alone, 127 = 127 or more); eqb: place in it
+        bool alone[CH_ITEMS], moved[CH_ITEMS], act[CH_ITEMS], prk[CH_ITEMS];
         u32 split_here = 0;
         if constexpr (WIDE) {
             // ---- every group of the tile ordered by one segmented sort of the workgroup ----
@@ -302,7 +331,7 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
             for (int j = 0; j < CH_ITEMS; j++) {
                 const u32 t = (u32)j * CH_THREADS + tid;
                 act[j] = t < plen;
-                dst[j] = t; newhead[j] = 0; alone[j] = false; moved[j] = false; ppos[j] = 0;
+                dst[j] = t; newhead[j] = 0; alone[j] = false; moved[j] = false; ppos[j] = 0; prk[j] = false; dl[j] = 0; nsz[j] = 0; eqb[j] = 0;
                 if (!act[j]) continue;
                 u32 w = (u32)j * (CH_THREADS / 64) + wv;
                 u64 m = rsm[j] & le;
@@ -312,11 +341,25 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
                 const u32 p = key[src[j]];
                 myp[j] = p;
                 newhead[j] = hd2[WIDE ? gst[j] : 0] + less;
+                dl[j] = less;
+                eqb[j] = t - rbeg;
                 alone[j] = rstart[j] && rend[j];
-                moved[j] = less != 0;
+                // where the next run starts (the start words hold the runs' by now): the run's length, and whether the run is its whole group
+                u32 nx;
+                {
+                    u32 w2 = (u32)j * (CH_THREADS / 64) + wv;
+                    u64 ab = rsm[j] & ~le;
+                    while (ab == 0ull && w2 + 1 < CH_WORDS) { w2++; ab = startm[w2]; }
+                    nx = ab ? w2 * 64u + (u32)__ffsll((unsigned long long)ab) - 1u : plen;
+                    if (nx > plen) nx = plen;
+                }
+                const u32 rlen = nx - rbeg;
+                nsz[j] = alone[j] ? 0u : (rlen < 127u ? rlen : 127u);
+                const bool whole = less == 0 && (nx >= plen || (hd[nx] >> 16) != gst[j]);
+                moved[j] = !whole;                                       // (its rank or its group's size changes: a record either way)
                 split_here |= less != 0 ? 1u : 0u;
                 if (!alone[j] && t - rbeg >= CH_CAP) s_wide = 1;        // a run of more than CH_CAP members stays: the chunk stays WIDE
-                if (CYCLIC && out && alone[j] && !prev.P) {
+                if (CYCLIC && out && (alone[j] || (PARK && moved[j])) && !prev.P) {
                     if (FSL) {
                         u32 f = fdir[p >> dsh];
                         while (f + 1 < k32 && ftab[f + 1].x <= p) f++;
@@ -381,6 +424,9 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
             if (act[j]) {
                 key[j * CH_THREADS + tid] = my_key[j];
                 if (NKEYS == 3) key23[NKEYS == 3 ? j * CH_THREADS + tid : 0] = my_key23[NKEYS == 3 ? j : 0];
+                // (the heads in hd have been read by everyone: the start words say the rest) link code of this member: its successor's
+                // rank when that successor is tied in a group of this group's size, else a value no rank takes among tied elements
+                if (PARK && park) hd[j * CH_THREADS + tid] = (sz[j] <= CH_PARK_MAX && (s1i[PARK ? j : 0] & 0x17fu) == sz[j]) ? s1r[PARK ? j : 0] : 0xffffffffu;
             }
         __syncthreads();
         CH_MARK(2);
@@ -388,9 +434,11 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++) {
             const u32 sl = (u32)j * CH_THREADS + tid;
-            dst[j] = sl; newhead[j] = 0; alone[j] = false; moved[j] = false;
+            dst[j] = sl; newhead[j] = 0; alone[j] = false; moved[j] = false; prk[j] = false; dl[j] = 0; nsz[j] = 0; eqb[j] = 0;
             if (!act[j]) continue;
             const u32 g0 = gs[j], gsz = sz[j], mine = key[sl];
+            const u32 mylink = (PARK && park) ? hd[sl] : 0xffffffffu;
+            u32 unlike = 0;                         // members whose link code differs from mine
             u32 less = 0, eq = 0, eq_before = 0;
             if (NKEYS == 3) {
                 const u64 mine23 = key23[NKEYS == 3 ? sl : 0];
@@ -399,6 +447,10 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
                     u32 ko[4]; u64 ko23[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) { ko[q] = key[g0 + m + q]; ko23[q] = key23[NKEYS == 3 ? g0 + m + q : 0]; }
+                    if (PARK && park) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) unlike |= hd[g0 + m + q] ^ mylink;
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const bool same = ko[q] == mine && ko23[q] == mine23;
@@ -410,6 +462,7 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
                 for (; m < gsz; m++) {
                     const u32 ko = key[g0 + m];
                     const u64 ko23 = key23[NKEYS == 3 ? g0 + m : 0];
+                    if (PARK && park) unlike |= hd[g0 + m] ^ mylink;
                     const bool same = ko == mine && ko23 == mine23;
                     less += (ko < mine || (ko == mine && ko23 < mine23)) ? 1u : 0u;
                     eq += same ? 1u : 0u;
@@ -418,41 +471,74 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
             } else {
                 for (u32 m = 0; m < gsz; m++) {
                     const u32 ko = key[g0 + m];
+                    if (PARK && park) unlike |= hd[g0 + m] ^ mylink;
                     less += ko < mine ? 1u : 0u;
                     eq += ko == mine ? 1u : 0u;
                     eq_before += (ko == mine && g0 + m < sl) ? 1u : 0u;
                 }
             }
+            if (PARK && park && mylink != 0xffffffffu && unlike == 0) {
+                // every member's successor lies in ONE tied group of this group's size: the group parks behind it (see PARKED CHAINS)
+                prk[j] = true;
+                nsz[j] = gsz;
+                continue;
+            }
             dst[j] = g0 + less + eq_before;
-            newhead[j] = hd[sl] + less;
+            newhead[j] = myh[j] + less;
+            dl[j] = less;
+            eqb[j] = eq_before;
+            nsz[j] = eq == 1 ? 0u : (eq < 127u ? eq : 127u);
             alone[j] = eq == 1;
-            moved[j] = less != 0;
+            moved[j] = less != 0 || eq < gsz;                       // (its rank or its group's size changes: a record either way)
             split_here |= eq < gsz ? 1u : 0u;
         }
         }
         CH_MARK(3);
         u32 pv[CH_ITEMS];
-#pragma unroll
-        for (int j = 0; j < CH_ITEMS; j++) pv[j] = (out && act[j] && alone[j]) ? (prev.P ? (u32)prev.P[myp[j]] : (u32)prev.T[ppos[j]]) : 0u;
-#pragma unroll
-        for (int j = 0; j < CH_ITEMS; j++)
-            if (act[j] && !alone[j]) atomicOr((unsigned long long *)&keepm[dst[j] >> 6], 1ull << (dst[j] & 63u));
-        // new ranks: to the chunk's move list (any order)
+        bool wr[CH_ITEMS];
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++) {
-            const bool mvd = act[j] && moved[j];
+            // (a member whose cyclic predecessor is parked behind it needs no byte: its whole group has ONE previous byte, in place since
+            // round 0 -- ChainCtx::at.  ppos is that predecessor when the factors sit in LDS and no previous-symbol array exists)
+            // With parked chains every member of a group that splits writes, alone or not, to its place in its new group's slots
+            // (ChainCtx::at says why); without them a member writes once, when it is alone.
+            wr[j] = out && act[j] && !prk[j] && (alone[j] || (PARK && moved[j]));
+            if (PARK) wr[j] = wr[j] && !(!prev.P && (pinfo[ppos[j]] & 0x80u));
+            pv[j] = wr[j] ? (prev.P ? (u32)prev.P[myp[j]] : (u32)prev.T[ppos[j]]) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++)
+            if (act[j] && !alone[j] && !prk[j]) atomicOr((unsigned long long *)&keepm[dst[j] >> 6], 1ull << (dst[j] & 63u));
+        // members of groups that park: the flag in position space (the group's size stays as it is), and they are gone from the list
+        if (PARK && park) {
+            u32 np = 0;
+#pragma unroll
+            for (int j = 0; j < CH_ITEMS; j++)
+                if (act[j] && prk[j]) { pinfo[myp[j]] = (u8)(nsz[j] | 0x80u); np++; }
+            const u64 any = __ballot(np != 0);
+            if (any) {
+                u32 tot = np;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) tot += (u32)__shfl_xor((int)tot, d, 64);
+                if (lane == 0) atomicAdd(&s_npark, tot);
+            }
+        }
+        // what happened to the members whose rank or group changed: to the chunk's record list (any order)
+#pragma unroll
+        for (int j = 0; j < CH_ITEMS; j++) {
+            const bool mvd = act[j] && !prk[j] && (PARK ? (moved[j] || alone[j]) : dl[j] != 0);
             const u64 mm = __ballot(mvd);
             if (mm) {
                 const int leader = __ffsll((unsigned long long)mm) - 1;
                 u32 b0 = 0;
                 if (lane == leader) b0 = atomicAdd(&s_nmv, (u32)__popcll(mm));
                 b0 = shfl_t(b0, leader);
-                if (mvd) mv[base + b0 + (u32)__popcll(mm & (le >> 1))] = ((u64)newhead[j] << 32) | (u64)myp[j];
+                if (mvd) mv[base + b0 + (u32)__popcll(mm & (le >> 1))] = PARK ? CH_REC(myp[j], dl[j], nsz[j], alone[j], eqb[j]) : (((u64)newhead[j] << 32) | (u64)myp[j]);
             }
         }
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++)
-            if (out && act[j] && alone[j]) out[newhead[j]] = (u8)pv[j];
+            if (wr[j]) out[newhead[j] + (PARK ? eqb[j] : 0u)] = (u8)pv[j];
         if (split_here) s_split = 1;
         __syncthreads();
         CH_MARK(4);
@@ -467,7 +553,7 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
         // tile is behind the barriers above, so nothing unread is overwritten
 #pragma unroll
         for (int j = 0; j < CH_ITEMS; j++)
-            if (act[j] && !alone[j]) {
+            if (act[j] && !alone[j] && !prk[j]) {
                 const u32 w = dst[j] >> 6, b = dst[j] & 63u;
                 const u64 lowbits = keepm[w] & ((1ull << b) - 1ull);
                 const u32 o = wp + kpre[w] + (u32)__popcll(lowbits);
@@ -483,6 +569,7 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
     if (tid0 == 0) {
         ccount[c] = wp;
         mvcount[c] = s_nmv;
+        if (PARK && s_npark) atomicAdd(&result[CHS_PARKED], (unsigned long long)s_npark);
         if (WIDE && !s_wide) cwide[c] = 0;          // only groups of up to CH_CAP members are left: the other instantiation takes over
         if (s_split && __hip_atomic_load(&result[CHS_SPLIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
             __hip_atomic_store(&result[CHS_SPLIT], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -494,26 +581,225 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
 #undef CH_MARK
 }
 
-// rank[position] = new rank for everything a round moved; runs when every gather of the round is done
-__global__ __launch_bounds__(256) void chunk_apply_moves_kernel(const u64 *__restrict__ mv, const u32 *__restrict__ cstart, const u32 *__restrict__ mvcount,
-                                                                u32 *__restrict__ rank)
+// ---- the record pass: runs when every gather of the round is done ---------------------------------------------------------------
+// A record says what the round did to one member q: rank[q] += delta, pinfo[q] = new size (0: alone).  The same then happens to the
+// positions q - 1, q - 2, ... while they carry the parked flag -- the chain behind q (PARKED CHAINS above) -- and a position whose
+// member came out alone gets its output byte there (and, in the final lay-out, its suffix-array slot).  A chain never leaves q's
+// factor (a parked position is never its factor's last one), so the only position whose previous symbol is not the byte before it
+// is the factor's first.  The record's own lane walks up to CH_SHORT_CHAIN positions; longer chains are finished by the workgroup's
+// waves, 64 positions per step (pass 2 of the kernel).
+struct ChainCtx {
+    u32 *rank; u8 *pinfo; PrevSym prev; u8 *out; u32 *SA;
+    // (the byte of a chain position that starts its factor is not the byte before it: those few are put right by
+    // chunk_factor_heads_kernel when the rounds are over, instead of a factor search per chain here)
+    __device__ __forceinline__ u8 byte_before(u32 x) const { return prev.P ? prev.P[x] : prev.T[x ? x - 1u : 0u]; }
+    // One chain position.  OUTPUT BYTES.  Kept true for every tied group, refined or parked: its slots [head, head + size) hold its
+    // members' previous bytes, in SOME order (round 0's carried bytes start it; every member of a group that splits writes its byte to
+    // its place in its new group's slots, alone or not).  A position x whose predecessor x - 1 is parked too then never needs a byte
+    // written: the group parked at x - 1 is, member for member, the set of predecessors of x's group, so all of that group's members
+    // have the SAME previous byte and any split of its slots holds the right bytes already.  Only the chain's lowest position
+    // (`last`) may sit in a group with different bytes: it writes like a member of a refined group.  A member that came out alone leaves no
+    // group size to keep (its rank is unique now: no group's successors can all point at it), so pinfo is only written for members
+    // that stay tied; the parked flag of a finished chain stays set -- nothing ever walks there again.
+    __device__ __forceinline__ void at(u32 x, u32 r, u32 delta, u32 size7, bool alone, bool last, u32 eqb) const
+    {
+        const u32 nr = r + delta;
+        if (delta) rank[x] = nr;
+        if (!alone) pinfo[x] = (u8)(size7 | 0x80u);
+        if (out && last) out[nr + eqb] = byte_before(x);
+        if (alone && SA) SA[nr] = x;
+    }
+};
+// when the rounds are over (ranks final): the output byte of every factor's first position is its factor's last byte (mk_bwts_sa.c:172-188)
+__global__ __launch_bounds__(256) void chunk_factor_heads_kernel(const u8 *__restrict__ T, u64 n, const u32 *__restrict__ fstart, u64 k, const u32 *__restrict__ rank,
+                                                                 u8 *__restrict__ out)
 {
+    const u64 f = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (f >= k) return;
+    const u64 s0 = fstart[f], e1 = f + 1 < k ? (u64)fstart[f + 1] : n;
+    out[rank[s0]] = T[e1 - 1];
+}
+#define CH_REC_POS(e)   ((u32)(e))
+#define CH_REC_DELTA(e) ((u32)((e) >> 32) & 0xfffu)
+#define CH_REC_SIZE(e)  ((u32)((e) >> 44) & 0x7fu)
+#define CH_REC_ALONE(e) ((((e) >> 51) & 1ull) != 0)
+#define CH_REC_EQB(e)   ((u32)((e) >> 53))           /* the member's place inside its new group (0 when alone) */
+
+// how many of the positions q - 1, q - 2, ... q - 8 (in this order) carry the parked flag before the first that does not: 0 .. 8
+__device__ __forceinline__ u32 chain_peek8(const u8 *__restrict__ pinfo, u32 q)
+{
+    if (q < 8u) { u32 c = 0; while (c < q && (pinfo[q - 1u - c] & 0x80u)) c++; return c; }
+    const u64 a = (u64)(q - 8u) & ~7ull;                       // (pinfo is allocated in multiples of 256 bytes: a + 16 <= its end)
+    const u64 lo = *(const u64 *)(pinfo + a), hi = *(const u64 *)(pinfo + a + 8);
+    const u32 sh = (u32)((u64)(q - 8u) - a) * 8u;
+    const u64 w = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;   // byte 7 = position q - 1 ... byte 0 = position q - 8
+    const u64 clear = ~(w | 0x7f7f7f7f7f7f7f7full);            // top bit of a byte set <=> that position is NOT parked
+    return clear ? (u32)__clzll((long long)clear) >> 3 : 8u;
+}
+
+// pass 1, a lane per record: the member itself and the first CH_SHORT_CHAIN (= 8: one peek) positions of its chain.  Records whose chain goes
+// on are kept, compacted to the front of the chunk's own record list (never ahead of the records still to be read); lcount[c] says how many.
+// MODE 0: the rounds without parked chains: a record is (new rank << 32 | position) of a member whose rank changed, nothing else to do.
+// MODE 1: their final lay-out of equal words: the same records for every member left, with its byte and suffix-array slot.  MODE 2: the above.
+template <int MODE>
+__global__ __launch_bounds__(256) void chunk_apply_records_kernel(u64 *__restrict__ mv, const u32 *__restrict__ cstart, const u32 *__restrict__ mvcount, ChainCtx cx,
+                                                                  u32 *__restrict__ lcount)
+{
+    if (MODE != 2) {
+        const u32 c = blockIdx.x;
+        const u32 m = mvcount[c];
+        const u64 base = cstart[c];
+        for (u32 i = threadIdx.x; i < m; i += 256) {
+            const u64 e = mv[base + i];
+            const u32 q = (u32)e, nr = (u32)(e >> 32);
+            cx.rank[q] = nr;
+            if (MODE == 1) {
+                if (cx.out) cx.out[nr] = cx.prev((u64)q);
+                if (cx.SA) cx.SA[nr] = q;
+            }
+        }
+        return;
+    }
+    static_assert(CH_SHORT_CHAIN == 8, "chain_peek8 looks at eight positions");
+    __shared__ u32 s_long;
     const u32 c = blockIdx.x;
     const u32 m = mvcount[c];
     const u64 base = cstart[c];
-    for (u32 i = threadIdx.x; i < m; i += 256) { const u64 e = mv[base + i]; rank[(u32)e] = (u32)(e >> 32); }
+    const int lane = lane_id();
+    if (threadIdx.x == 0) s_long = 0;
+    __syncthreads();
+    for (u32 i0 = 0; i0 < m; i0 += 256) {
+        const u32 i = i0 + threadIdx.x;
+        bool lng = false;
+        u64 e = 0;
+        if (i < m) {
+            e = mv[base + i];
+            const u32 q = CH_REC_POS(e), delta = CH_REC_DELTA(e), size7 = CH_REC_SIZE(e);
+            const bool alone = CH_REC_ALONE(e);
+            const u32 cl = cx.pinfo ? chain_peek8(cx.pinfo, q) : 0u;
+            u32 nr = 0;
+            if (delta || (e & CH_REC_SELF)) { nr = cx.rank[q] + delta; if (delta) cx.rank[q] = nr; }
+            if (cx.pinfo && !alone) cx.pinfo[q] = (u8)size7;
+            if (e & CH_REC_SELF) {
+                if (cx.out) cx.out[nr] = cx.prev((u64)q);
+                if (cx.SA) cx.SA[nr] = q;
+            }
+            if (cl) {
+                lng = cl == 8u && q > 8u && (cx.pinfo[q - 9u] & 0x80u);
+                // a member that came out alone without changing its rank changes nothing along its chain but the lowest position's byte
+                const bool walk = delta != 0 || !alone || cx.SA != nullptr;
+                if (walk) {
+                    u32 r[8];
+#pragma unroll
+                    for (u32 t = 0; t < 8; t++) r[t] = t < cl ? cx.rank[q - 1u - t] : 0u;
+#pragma unroll
+                    for (u32 t = 0; t < 8; t++) if (t < cl) cx.at(q - 1u - t, r[t], delta, size7, alone, !lng && t + 1 == cl, CH_REC_EQB(e));
+                } else if (!lng && cx.out) {
+                    const u32 x = q - cl;
+                    cx.out[cx.rank[x]] = cx.byte_before(x);
+                }
+            }
+        }
+        __syncthreads();                              // every record of this step has been read
+        const u64 lm = __ballot(lng);
+        if (lm) {
+            const int leader = __ffsll((unsigned long long)lm) - 1;
+            u32 b0 = 0;
+            if (lane == leader) b0 = atomicAdd(&s_long, (u32)__popcll(lm));
+            b0 = shfl_t(b0, leader);
+            if (lng) mv[base + b0 + (u32)__popcll(lm & lanemask_lt())] = e;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) lcount[c] = s_long;
 }
 
-// elements still tied over all chunks (one workgroup: at most a few 10^4 chunks)
-__global__ __launch_bounds__(1024) void chunk_total_kernel(const u32 *__restrict__ ccount, u32 nchunks, unsigned long long *__restrict__ result)
+// pass 2, a wave per kept record; every wave takes a contiguous share of all chunks' kept records (loff: exclusive sums of lcount, the
+// total behind them; one search for the share's first chunk, then a walk): the chain from position q - 1 - CH_SHORT_CHAIN downwards,
+// 64 positions per step; flag and rank of a step's positions are fetched together, so a step costs one memory round trip.
+__global__ __launch_bounds__(256) void chunk_long_chains_kernel(const u64 *__restrict__ mv, const u32 *__restrict__ cstart, const u32 *__restrict__ loff, u32 nchunks,
+                                                                ChainCtx cx)
+{
+    const int lane = lane_id();
+    const u32 total = loff[nchunks];
+    const u32 wave0 = (u32)(((u64)blockIdx.x * 256 + threadIdx.x) >> 6), waves = (u32)(((u64)gridDim.x * 256) >> 6);
+    const u32 per = (total + waves - 1) / waves;
+    const u32 t0 = wave0 * per < total ? wave0 * per : total, t1 = t0 + per < total ? t0 + per : total;
+    if (t0 >= t1) return;
+    u32 c = 0;
+    { u32 lo = 0, hi = nchunks - 1; while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (loff[mid] <= t0) lo = mid; else hi = mid - 1; } c = lo; }
+    u32 cend = loff[c + 1];
+    for (u32 t = t0; t < t1; t++) {
+        while (t >= cend) { c++; cend = loff[c + 1]; }
+        const u64 e = mv[(u64)cstart[c] + (t - loff[c])];
+        const u32 q = CH_REC_POS(e), delta = CH_REC_DELTA(e), size7 = CH_REC_SIZE(e);
+        const bool alone = CH_REC_ALONE(e);
+        long long x0 = (long long)q - 1 - CH_SHORT_CHAIN;
+        const bool walk = delta != 0 || !alone || cx.SA != nullptr;     // (else only the chain's end matters: flags alone are read on the way)
+        for (;;) {
+            const long long x = x0 - (long long)lane;
+            const u64 xc = x >= 0 ? (u64)x : 0ull;
+            const u32 fl = cx.pinfo[xc];
+            const u32 r = walk ? cx.rank[xc] : 0u;
+            const long long xn = x0 - 64;                                 // the next step's first position: is the chain going on there?
+            const bool goes_on = xn >= 0 && (cx.pinfo[xn >= 0 ? xn : 0] & 0x80u);
+            const bool ok = x >= 0 && (fl & 0x80u);
+            const u64 mk = __ballot(ok);
+            const int cnt = mk == ~0ull ? 64 : __ffsll((unsigned long long)~mk) - 1;      // parked positions from the top of these 64
+            const bool last = lane + 1 == cnt && !(cnt == 64 && goes_on);
+            if (lane < cnt) {
+                if (walk) cx.at((u32)xc, r, delta, size7, alone, last, CH_REC_EQB(e));
+                else if (last && cx.out) cx.out[cx.rank[xc]] = cx.byte_before((u32)xc);
+            }
+            if (cnt < 64 || !goes_on) break;
+            x0 -= 64;
+        }
+    }
+}
+
+// elements still tied over all chunks, and the exclusive sums of the chunks' kept-record counts for chunk_long_chains_kernel (one
+// workgroup: at most a few 10^4 chunks)
+__global__ __launch_bounds__(1024) void chunk_total_kernel(const u32 *__restrict__ ccount, u32 nchunks, unsigned long long *__restrict__ result,
+                                                           const u32 *__restrict__ lcount, u32 *__restrict__ loff)
 {
     __shared__ u64 sm[16];
+    __shared__ u32 carry;
     u64 s = 0;
     for (u32 i = threadIdx.x; i < nchunks; i += 1024) s += ccount[i];
     s = wave_scan_inclusive(s, OpAdd());
     if (lane_id() == 63) sm[wave_id()] = s;
+    if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     if (threadIdx.x == 0) { u64 t = 0; for (int w = 0; w < 16; w++) t += sm[w]; result[CHS_TOTAL] = t; }
+    if (!lcount) return;
+    __shared__ u32 wtot[16];
+    for (u32 i0 = 0; i0 < nchunks; i0 += 1024) {
+        const u32 i = i0 + threadIdx.x;
+        const u32 v = i < nchunks ? lcount[i] : 0u;
+        const u32 inc = wave_scan_inclusive(v, OpAdd());
+        __syncthreads();                                      // (wtot / carry of the previous step have been read)
+        if (lane_id() == 63) wtot[wave_id()] = inc;
+        __syncthreads();
+        u32 before = carry;
+        for (int w = 0; w < wave_id(); w++) before += wtot[w];
+        if (i < nchunks) loff[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) loff[nchunks] = carry;
+}
+
+// When most of the list has settled (or parked) the chunks are nearly empty, and a round pays a workgroup's set-up per chunk for a handful
+// of elements: the survivors are then copied, chunk after chunk (groups stay whole and in order), into the other pair of list arrays and
+// new chunks are cut over the dense list.  off: exclusive sums of ccount.
+__global__ __launch_bounds__(256) void chunk_compact_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, const u32 *__restrict__ cstart,
+                                                            const u32 *__restrict__ ccount, const u32 *__restrict__ off, u32 *__restrict__ nidx, u32 *__restrict__ nhead)
+{
+    const u32 c = blockIdx.x;
+    const u64 base = cstart[c], o = off[c];
+    const u32 cnt = ccount[c];
+    for (u32 i = threadIdx.x; i < cnt; i += 256) { nidx[o + i] = idx[base + i]; nhead[o + i] = head[base + i]; }
 }
 
 // chunks c0 .. c0 + nch over list slots [lo, hi): chunk i nominally starts at lo + i * S, actually at the first group start at
@@ -562,9 +848,11 @@ __global__ __launch_bounds__(256) void chunk_init_kernel(const u32 *__restrict__
     }
 }
 
-// what is left when no group splits any more (equal infinite words): the members take their group's slots in list order
-__global__ __launch_bounds__(256) void chunk_rest_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, const u32 *__restrict__ cstart,
-                                                         const u32 *__restrict__ ccount, PrevSym prev, u8 *__restrict__ out, u32 *__restrict__ SA)
+// what is left when no group splits any more (equal infinite words): the members take their group's slots in list order -- as records
+// (delta = place in the group, alone, own byte and suffix-array slot written by the record pass), so that the chains parked behind
+// them are laid out the same way
+__global__ __launch_bounds__(256) void chunk_rest_records_kernel(const u32 *__restrict__ idx, const u32 *__restrict__ head, const u32 *__restrict__ cstart,
+                                                                 const u32 *__restrict__ ccount, u64 *__restrict__ mv, u32 *__restrict__ mvcount, bool parked)
 {
     const u32 c = blockIdx.x;
     const u64 base = cstart[c];
@@ -573,10 +861,9 @@ __global__ __launch_bounds__(256) void chunk_rest_kernel(const u32 *__restrict__
         const u32 hh = head[base + i];
         u32 o = 0;
         while (o < i && head[base + i - o - 1] == hh) o++;
-        const u32 slot = hh + o, p = idx[base + i];
-        if (out) out[slot] = prev(p);
-        if (SA) SA[slot] = p;
+        mv[base + i] = parked ? CH_REC(idx[base + i], o, 0u, true, 0u) | CH_REC_SELF : (((u64)(hh + o) << 32) | (u64)idx[base + i]);
     }
+    if (threadIdx.x == 0) mvcount[c] = cnt;
 }
 
 // ---- the one-off order, by GROUP RECORDS ----------------------------------------------------------------------------------------
@@ -662,16 +949,78 @@ __global__ __launch_bounds__(DG_THREADS) void go_write_kernel(const u32 *__restr
 }
 // record forms (go_write_kernel): pairs == false: (head = SA slot of the first member << 32 | smallest position, size); pairs == true:
 // bit 63 set: the same with the flag; bit 63 clear: a group of two, (larger position << 32 | smaller position, head)
+// STATIC PARKING (see PARKED CHAINS at the top).  The records are sorted by smallest position, so the group of a record's successors, if it
+// is a group at all, is the NEXT record: record r is linked when record r + 1 holds exactly its members' successors (same size, member for
+// member one position on -- the members of a group stand in position order since round 0's stable sort -- and no member ends its factor).
+// A record with GO_RUN_MIN linked records in a row from itself on lies in a long repeat, GO_RUN_MIN groups or more from its end: its
+// members never enter the list; they are parked at once (flag + size in pinfo), behind the records nearer the repeat's end, which are
+// refined (and park one by one, dynamically, once they are what leads the chain).  Short runs stay in the list whole: chains of a few
+// positions cost more in the record pass than their groups cost in the two or three rounds that settle them.
+#define GO_RUN_MIN 64
+__global__ __launch_bounds__(256) void go_link_kernel(const u64 *__restrict__ rk, const u32 *__restrict__ rv, u64 groups, const u32 *__restrict__ SA, bool pairs,
+                                                      const u32 *__restrict__ fstart, u32 k, u64 n, u64 *__restrict__ linkw)
+{
+    __shared__ u32 fs[CH_FS];
+    for (u32 i = threadIdx.x; i < k; i += 256) fs[i] = fstart[i];
+    __syncthreads();
+    // is x the last position of its factor?  <=> x + 1 starts a factor, or x ends the text
+    auto fend = [&](u32 x) -> bool {
+        if ((u64)x + 1 >= n) return true;
+        u32 lo = 0, hi = k;                       // first factor start > x
+        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (fs[mid] > x) hi = mid; else lo = mid + 1; }
+        return lo < k && fs[lo] == x + 1u;
+    };
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    bool link = false;
+    if (r + 1 < groups) {
+        const u64 k0 = rk[r], k1 = rk[r + 1];
+        if (pairs && !(k0 >> 63)) {
+            if (!(k1 >> 63)) {
+                const u32 mn = (u32)k0, mx = (u32)(k0 >> 32);
+                link = (u32)k1 == mn + 1u && (u32)(k1 >> 32) == mx + 1u && !fend(mn) && !fend(mx);
+            }
+        } else if (!pairs || (k1 >> 63)) {
+            const u32 sz = rv[r];
+            if (sz == rv[r + 1] && sz <= CH_PARK_MAX && (u32)k1 == (u32)k0 + 1u) {
+                const u32 hm = pairs ? 0x7fffffffu : 0xffffffffu;
+                const u64 h0 = (u32)(k0 >> 32) & hm, h1 = (u32)(k1 >> 32) & hm;
+                link = true;
+                for (u32 i = 0; i < sz; i++) {
+                    const u32 a = SA[h0 + i];
+                    if (SA[h1 + i] != a + 1u || fend(a)) { link = false; break; }
+                }
+            }
+        }
+    }
+    const u64 m = __ballot(link);
+    if (lane_id() == 0) linkw[r >> 6] = m;
+}
+// GO_RUN_MIN (= 64) link bits from record r on, all set?  (linkw: two zero words behind the last)
+__device__ __forceinline__ bool go_parked(const u64 *__restrict__ linkw, u64 r)
+{
+    static_assert(GO_RUN_MIN == 64, "one funnel of two words");
+    if (!linkw) return false;
+    const u64 w = r >> 6;
+    const u32 b = (u32)r & 63u;
+    const u64 lo = linkw[w], hi = linkw[w + 1];
+    return (b ? (lo >> b) | (hi << (64u - b)) : lo) == ~0ull;
+}
 struct GoSizeIn {
-    const u64 *rk; const u32 *rv; bool pairs;
-    __device__ __forceinline__ u32 operator()(u64 j) const { return (pairs && !(rk[j] >> 63)) ? 2u : rv[j]; }
+    const u64 *rk; const u32 *rv; bool pairs; const u64 *linkw;
+    __device__ __forceinline__ u32 operator()(u64 j) const { return go_parked(linkw, j) ? 0u : ((pairs && !(rk[j] >> 63)) ? 2u : rv[j]); }
 };
+// elements that enter the list: the last record's offset + its size
+__global__ void go_listed_kernel(const u32 *doff, GoSizeIn zin, u64 groups, u64 *out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = groups ? (u64)doff[groups - 1] + (u64)zin(groups - 1) : 0ull;
+}
 // members of the sorted groups to their places: a pair comes out of its record; the others are read from the suffix array itself -- a
 // group is the slot range [head, head + size) there, and all its members carry that head -- a lane copying its own group when it is
 // short, the wave together the longer ones (one scattered read per group)
 __global__ __launch_bounds__(256) void go_expand_kernel(const u64 *__restrict__ rkeys, const u32 *__restrict__ rvals, const u32 *__restrict__ doff, u64 groups,
                                                         const u32 *__restrict__ SA, u32 *__restrict__ st_idx, u32 *__restrict__ st_head,
-                                                        bool pairs)
+                                                        bool pairs, u8 *__restrict__ pinfo /* null, or: every member's group size goes there (PARKED CHAINS) */,
+                                                        const u64 *__restrict__ linkw /* null, or: go_link_kernel's bits (static parking) */)
 {
     const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
     const int lane = lane_id();
@@ -680,9 +1029,17 @@ __global__ __launch_bounds__(256) void go_expand_kernel(const u64 *__restrict__ 
         const u64 k = rkeys[j];
         const u32 v = rvals[j];
         d = doff[j];
-        if (pairs && !(k >> 63)) {
+        if (go_parked(linkw, j)) {
+            // parked from the start: no list entry, the flag in position space (the loops below see a group of size 0)
+            if (pairs && !(k >> 63)) { pinfo[(u32)k] = (u8)(2u | 0x80u); pinfo[(u32)(k >> 32)] = (u8)(2u | 0x80u); }
+            else {
+                const u32 hd = (u32)(k >> 32) & (pairs ? 0x7fffffffu : 0xffffffffu);
+                for (u32 t = 0; t < v; t++) pinfo[SA[(u64)hd + t]] = (u8)(v | 0x80u);
+            }
+        } else if (pairs && !(k >> 63)) {
             st_idx[d] = (u32)k; st_idx[d + 1] = (u32)(k >> 32);
             st_head[d] = v; st_head[d + 1] = v;
+            if (pinfo) { pinfo[(u32)k] = 2; pinfo[(u32)(k >> 32)] = 2; }
         } else { e = (u32)(k >> 32) & (pairs ? 0x7fffffffu : 0xffffffffu); sz = v; }
     }
     if (sz && sz <= 4) {
@@ -690,14 +1047,18 @@ __global__ __launch_bounds__(256) void go_expand_kernel(const u64 *__restrict__ 
 #pragma unroll
         for (u32 t = 0; t < 4; t++) pi[t] = t < sz ? SA[(u64)e + t] : 0u;
 #pragma unroll
-        for (u32 t = 0; t < 4; t++) if (t < sz) { st_idx[d + t] = pi[t]; st_head[d + t] = e; }
+        for (u32 t = 0; t < 4; t++) if (t < sz) { st_idx[d + t] = pi[t]; st_head[d + t] = e; if (pinfo) pinfo[pi[t]] = (u8)sz; }
     }
     u64 longm = __ballot(sz > 4);
     while (longm) {
         const int r = __ffsll((unsigned long long)longm) - 1;
         longm &= longm - 1;
         const u32 re = shfl_t(e, r), rs = shfl_t(sz, r), rd = shfl_t(d, r);
-        for (u32 t = (u32)lane; t < rs; t += 64) { st_idx[rd + t] = SA[(u64)re + t]; st_head[rd + t] = re; }
+        for (u32 t = (u32)lane; t < rs; t += 64) {
+            const u32 pp = SA[(u64)re + t];
+            st_idx[rd + t] = pp; st_head[rd + t] = re;
+            if (pinfo) pinfo[pp] = (u8)(rs < 127u ? rs : 127u);
+        }
     }
 }
 
@@ -740,17 +1101,17 @@ struct BlOut {
 struct BlRegroupOut {
     const u64 *bk; const u32 *bv; const u32 *oldhead; u64 m; int rb;
     u32 *t_idx; u32 *t_head; u32 *rank; PrevSym prev; u8 *out; unsigned long long *result;
-    const u32 *src; const u64 *k23;
+    const u32 *src; const u64 *k23; bool all_bytes;
     __device__ __forceinline__ void operator()(u64 j, u64 v) const       // inclusive (max, max) scan value, see DgRegroupIn
     {
         const u32 gidx = (u32)(v >> 32) - 1u, sidx = (u32)v - 1u;
-        const bool last_of_sub = j + 1 == m || bk[j + 1] != bk[j] || (k23 && k23[src[j + 1]] != k23[src[j]]);
-        const bool alone = sidx == (u32)j && last_of_sub;
         const u32 newhead = oldhead[j] + (sidx - gidx);        // sorting keeps every group on its own slots, all holding its old head
         const u32 p = src ? bv[src[j]] : bv[j];
         t_idx[j] = p; t_head[j] = newhead;
         if (sidx != gidx) rank[p] = newhead;
-        if (alone && out) out[newhead] = prev(p);
+        // (with parked chains: the byte of every member at its place in its group's slots, alone or not -- ChainCtx::at)
+        const bool last_of_sub = j + 1 == m || bk[j + 1] != bk[j] || (k23 && k23[src[j + 1]] != k23[src[j]]);
+        if (out && (all_bytes || (sidx == (u32)j && last_of_sub))) out[newhead + ((u32)j - sidx)] = prev(p);
         const u64 splitm = __ballot(sidx != gidx);
         if (splitm && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1 &&
             __hip_atomic_load(&result[CHS_SPLIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
@@ -817,12 +1178,17 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
 #define CH_HIP(call) do { const hipError_t e__ = (call); if (e__ != hipSuccess) { ctx->last_hip = (int)e__; if (round_trace) fprintf(stderr, "[chunks] line %d: hip error %d\n", __LINE__, (int)e__); return BWTS_E_HIP; } } while (0)
 #define CH_FAIL(why) do { if (round_trace) fprintf(stderr, "[chunks] invariant: %s (round %u)\n", why, rounds); return BWTS_E_INTERNAL; } while (0)
     const size_t e4 = align_up((size_t)a0 * 4, 256), e8 = align_up((size_t)a0 * 8, 256);
-    const u32 S = chunk_nominal_size(a0);
+    u32 S = chunk_nominal_size(a0);
     const u64 maxchunks = a0 / S + 1024;                 // every append adds at most one ragged chunk; rounds are capped at 80
     const size_t ct4 = align_up((size_t)(maxchunks + 1) * 4, 256);
     char *base = nullptr, *ob = nullptr;
     const size_t ct1 = align_up((size_t)(maxchunks + 1), 256);
-    int rc = aux_reserve(ctx, 2 * e4 + e8 + 3 * ct4 + ct1, &base);
+    // parked chains (see the top of this file): cyclic sort with the factors in the round kernel's LDS; BWTS_PARK=0 switches them off
+    // (opt-in: measured, it does not pay on this chip -- profiles/history/r04_parked_chains.md -- and stays as a tested alternate path)
+    const bool parking = CYCLIC && k <= CH_FS && [ctx] { const char *e = bwts_knob(ctx, "BWTS_PARK"); return e && atoi(e) == 1; }();
+    const bool static_parking = parking && [ctx] { const char *e = bwts_knob(ctx, "BWTS_PARK_STATIC"); return e && atoi(e) == 1; }();
+    const size_t pin_bytes = parking ? align_up((size_t)n, 256) : 0;
+    int rc = aux_reserve(ctx, 4 * e4 + e8 + 5 * ct4 + ct1 + pin_bytes, &base);
     if (rc == BWTS_E_NOMEM) return BWTS_OK;
     CH_TRY(rc);
     rc = aux_reserve_slot(ctx, 1, 2 * e8 + 2 * e4, &ob);
@@ -833,6 +1199,10 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u64 *mv = (u64 *)(base + 2 * e4);
     u32 *cstart = (u32 *)(base + 2 * e4 + e8), *ccount = (u32 *)(base + 2 * e4 + e8 + ct4), *mvcount = (u32 *)(base + 2 * e4 + e8 + 2 * ct4);
     u8 *cwide = (u8 *)(base + 2 * e4 + e8 + 3 * ct4);
+    u32 *lcount = (u32 *)(base + 2 * e4 + e8 + 3 * ct4 + ct1), *loff = (u32 *)(base + 2 * e4 + e8 + 4 * ct4 + ct1);
+    u8 *pinfo = parking ? (u8 *)(base + 2 * e4 + e8 + 5 * ct4 + ct1) : nullptr;
+    u32 *alt_idx = (u32 *)(base + 2 * e4 + e8 + 5 * ct4 + ct1 + pin_bytes), *alt_head = (u32 *)(base + 3 * e4 + e8 + 5 * ct4 + ct1 + pin_bytes);   // (chunk_compact_kernel)
+    if (parking) CH_HIP(hipMemsetAsync(pinfo, 0, (size_t)n, ctx->stream));
     u64 *slots = ctx->d_small + SM_CHSLOT;
     const int rb = CYCLIC ? bitlen_u64(n - 1) : bitlen_u64(n);
     PrevSym prev{sp.carry_src, d_T, n, d_fstart, k};
@@ -841,7 +1211,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
 
     // ---- one-off order: group records sorted by the group's smallest position, members copied to their places; the larger groups'
     // members compacted behind them (see go_write_kernel) ----
-    u64 a_small = 0;
+    u64 a_small = 0, a_listed = 0;           // elements of the smaller groups; those of them that enter the list (the others are parked at once)
     {
         const u64 tiles = (a0 + DG_OWN - 1) / DG_OWN;
         const bool pairs = n <= 0x80000000ull;                        // (positions and list indices below 2^31)
@@ -852,7 +1222,10 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         u32 *rv[2] = {(u32 *)(ob + 2 * g8), (u32 *)(ob + 2 * g8 + g4)};
         u32 *doff = (u32 *)(ob + 2 * g8 + 2 * g4);
         u64 *tcount = (u64 *)(ob + 2 * g8 + 3 * g4);
-        if (2 * g8 + 3 * g4 + align_up((size_t)(tiles + 1) * 8, 256) > 2 * e8 + 2 * e4) CH_FAIL("order block too small");
+        const size_t tc_bytes = align_up((size_t)(tiles + 1) * 8, 256);
+        const u64 link_words = (gmax + 255) / 256 * 4 + 2;              // go_link_kernel's bits: a word per wave, two zero words behind
+        u64 *linkw = parking ? (u64 *)(ob + 2 * g8 + 3 * g4 + tc_bytes) : nullptr;
+        if (2 * g8 + 3 * g4 + tc_bytes + (parking ? align_up((size_t)link_words * 8, 256) : 0) > 2 * e8 + 2 * e4) CH_FAIL("order block too small");
         {
             SpanGuard g(ctx, BWTS_K_RERANK, a0, 14 * a0);
             go_count_kernel<<<dim3((unsigned)tiles), dim3(DG_THREADS), 0, ctx->stream>>>(cur.idx, cur.head, a0, tcount);
@@ -878,16 +1251,30 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             const int pb = bitlen_u64(n - 1);
             CH_TRY(radix_sort_pairs(ctx, op, groups, pb < 1 ? 1 : pb, &ores));
             SpanGuard g(ctx, BWTS_K_RERANK, a_small, 20 * a_small);
-            GoSizeIn zin{rk[ores], rv[ores], pairs};
+            const unsigned gblocks = (unsigned)((groups + 255) / 256);
+            if (!static_parking) linkw = nullptr;
+            if (static_parking) {
+                // static parking: records deep inside long repeats never enter the list (go_link_kernel)
+                CH_HIP(hipMemsetAsync(linkw + (u64)gblocks * 4, 0, 2 * sizeof(u64), ctx->stream));
+                go_link_kernel<<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(rk[ores], rv[ores], groups, SA, pairs, d_fstart, (u32)k, n, linkw);
+            }
+            GoSizeIn zin{rk[ores], rv[ores], pairs, linkw};
             ScanStoreArr<u32> zout{doff};
             CH_TRY((device_scan<false, u32>(ctx, groups, zin, zout, OpAdd(), 0u, sp.scan_temp)));
-            go_expand_kernel<<<dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, ctx->stream>>>(rk[ores], rv[ores], doff, groups, SA, st_idx, st_head, pairs);
+            go_expand_kernel<<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(rk[ores], rv[ores], doff, groups, SA, st_idx, st_head, pairs, pinfo, linkw);
             CH_HIP(hipGetLastError());
+            if (static_parking) {
+                // how much of the smaller groups did enter the list: the last record's offset + its size
+                go_listed_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(doff, zin, groups, slots + CHS_TOTAL);
+                CH_TRY(read_small(ctx, SM_CHSLOT, CH_SLOT_WORDS));
+                a_listed = ctx->h_small[SM_CHSLOT + CHS_TOTAL];
+                if (a_listed > a_small) CH_FAIL("listed elements");
+            } else a_listed = a_small;
         }
     }
     u64 m_big = a0 - a_small;
-    if (round_trace) fprintf(stderr, "[chunks] list %llu: in chunks %llu (nominal chunk %u), big list %llu\n", (unsigned long long)a0,
-                             (unsigned long long)a_small, S, (unsigned long long)m_big);
+    if (round_trace) fprintf(stderr, "[chunks] list %llu: in chunks %llu (parked at once: %llu; nominal chunk %u), big list %llu\n", (unsigned long long)a0,
+                             (unsigned long long)a_listed, (unsigned long long)(a_small - a_listed), S, (unsigned long long)m_big);
 
     // ---- big list buffers (the order sort's block, free again) ----
     const size_t m4 = align_up((size_t)m_big * 4, 256), m8 = align_up((size_t)m_big * 8, 256);
@@ -909,14 +1296,17 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     }
     // ---- chunks over the smaller groups ----
     u32 nchunks = 0;
-    u64 tail = a_small;                     // the store behind it is free: chunks leaving the big list are appended there
-    if (a_small) {
-        nchunks = (u32)((a_small + S - 1) / S);
-        chunk_init_kernel<<<dim3((nchunks + 3) / 4), dim3(256), 0, ctx->stream>>>(st_head, 0, a_small, S, 0, nchunks, cstart, ccount, mvcount, cwide, false);
+    // (the larger groups' members, which go_write_kernel left at [a_small, a0), are in the big list's own buffers by now: the store
+    // behind the listed elements is free, chunks leaving the big list are appended there)
+    if (a_listed < a_small) S = chunk_nominal_size(a_listed);
+    u64 tail = a_listed;
+    if (a_listed) {
+        nchunks = (u32)((a_listed + S - 1) / S);
+        chunk_init_kernel<<<dim3((nchunks + 3) / 4), dim3(256), 0, ctx->stream>>>(st_head, 0, a_listed, S, 0, nchunks, cstart, ccount, mvcount, cwide, false);
         CH_HIP(hipGetLastError());
     }
 
-    u64 a_chunks = a_small;                 // elements in chunks after the last evaluated round
+    u64 a_chunks = a_listed;                // elements in chunks after the last evaluated round
     bool wide_possible = false;             // some chunk may be flagged WIDE: the second instantiation is launched as well
     if (m_big) {
         // the one-off order left every group of more than CH_CAP members in the big list; those of up to CH_GROUP_MAX go to chunks right
@@ -953,6 +1343,9 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     u64 h = (u64)al.hstep;
     const int hshift = nk == 3 ? 2 : 1;
     bool finished = false, stable = false;
+    // (static parking has taken the long repeats out; what the first list round meets are short ones, settled sooner by refining them
+    // than by chains of a few positions: groups park dynamically from the second list round on)
+    u32 list_rounds = 0;
     while (!finished) {
 #ifdef CH_PROFILE
         const int B = 1;
@@ -966,8 +1359,9 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             hs[b] = h;
             if (nchunks) {
                 SpanGuard g(ctx, BWTS_K_ROUND, 0, 0);          // (elements and bytes are added below, once the round's true size is known)
-#define CH_LAUNCH(NK, FS, WD) chunk_round_kernel<CYCLIC, NK, FS, WD><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, cwide, mv, mvcount, \
-                                                                                                        sp.rank, n, h, d_fstart, k, prev, out, res)
+#define CH_LAUNCH_P(NK, FS, WD, PK) chunk_round_kernel<CYCLIC, NK, FS, WD, PK><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, cwide, mv, mvcount, \
+                                                                                                        sp.rank, n, h, d_fstart, k, prev, out, res, pinfo, (!static_parking || list_rounds > 0) ? 1u : 0u)
+#define CH_LAUNCH(NK, FS, WD) do { if (CYCLIC && FS && parking) CH_LAUNCH_P(NK, (CYCLIC && FS), WD, (CYCLIC && FS)); else CH_LAUNCH_P(NK, FS, WD, false); } while (0)
                 const bool fsl = CYCLIC && k <= CH_FS;
                 if (nk == 3) { if (fsl) CH_LAUNCH(3, CYCLIC, false); else CH_LAUNCH(3, false, false); }
                 else { if (fsl) CH_LAUNCH(1, CYCLIC, false); else CH_LAUNCH(1, false, false); }
@@ -977,6 +1371,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                     else { if (fsl) CH_LAUNCH(1, CYCLIC, true); else CH_LAUNCH(1, false, true); }
                 }
 #undef CH_LAUNCH
+#undef CH_LAUNCH_P
                 CH_HIP(hipGetLastError());
             }
             if (m_big) {
@@ -989,8 +1384,11 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             }
             if (nchunks) {
                 SpanGuard g(ctx, BWTS_K_ROUND, 0, 0);
-                chunk_apply_moves_kernel<<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(mv, cstart, mvcount, sp.rank);
-                chunk_total_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ccount, nchunks, res);
+                const ChainCtx cx{sp.rank, pinfo, prev, out, nullptr};
+                if (parking) chunk_apply_records_kernel<2><<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(mv, cstart, mvcount, cx, lcount);
+                else chunk_apply_records_kernel<0><<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(mv, cstart, mvcount, cx, lcount);
+                chunk_total_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ccount, nchunks, res, parking ? lcount : nullptr, loff);
+                if (parking) chunk_long_chains_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(mv, cstart, loff, nchunks, cx);
                 CH_HIP(hipGetLastError());
             }
             if (m_big) {
@@ -1026,7 +1424,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 }
                 SpanGuard g(ctx, BWTS_K_RERANK, m_big, 60 * m_big);
                 DgRegroupIn rin{sorted_k1, m_big, rb, src, nk == 3 ? k23 : nullptr};
-                BlRegroupOut rout{sorted_k1, positions, bl_head[blc], m_big, rb, t_idx, t_head, sp.rank, prev, out, res, src, nk == 3 ? k23 : nullptr};
+                BlRegroupOut rout{sorted_k1, positions, bl_head[blc], m_big, rb, t_idx, t_head, sp.rank, prev, out, res, src, nk == 3 ? k23 : nullptr, parking};
                 CH_TRY((device_scan<true, u64>(ctx, m_big, rin, rout, OpMax2(), (u64)0, sp.scan_temp)));
                 // (the sort buffers are free again: run starts and lengths go there)
                 BlRunIn nin{t_head};
@@ -1037,6 +1435,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 CH_TRY((device_scan<false, u64>(ctx, m_big, sin, sout, OpAdd(), (u64)0, sp.scan_temp)));
             }
             h = h > (1ull << 60) ? h : h << hshift;
+            list_rounds++;
         }
         CH_TRY(read_small(ctx, SM_CHSLOT, CH_SLOTS * CH_SLOT_WORDS));
         for (int b = 0; b < B; b++) {
@@ -1069,9 +1468,8 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 (void)hipMemset(ctx->d_small + SM_CHSLOT + 64, 0, 64 * 8 * sizeof(u64));
             }
 #endif
-            if (round_trace) fprintf(stderr, "[chunks] round %u h %llu: chunks %llu -> %llu, big list %llu -> stays %llu, leaves %llu\n", rounds,
-                                     (unsigned long long)hs[b], (unsigned long long)a_chunks, (unsigned long long)in_chunks, (unsigned long long)m_big,
-                                     (unsigned long long)m_stay, (unsigned long long)m_exit);
+            if (round_trace) fprintf(stderr, "[chunks] round %u h %llu: chunks %llu -> %llu (parked %llu), big list %llu -> stays %llu, leaves %llu\n", rounds,
+                                     (unsigned long long)hs[b], (unsigned long long)a_chunks, (unsigned long long)in_chunks, (unsigned long long)r[CHS_PARKED], (unsigned long long)m_big, (unsigned long long)m_stay, (unsigned long long)m_exit);
             if (m_exit) {
                 const u32 add = (u32)((m_exit + S - 1) / S);
                 if ((u64)nchunks + add > maxchunks) CH_FAIL("chunk table full");
@@ -1091,6 +1489,21 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             if (!CYCLIC && hs[b] >= n) CH_FAIL("suffixes still tied at h >= n");      // suffixes are distinct; cannot happen
             if (rounds > 80) CH_FAIL("more than 80 rounds");
         }
+        if (!finished && nchunks >= 64 && a_chunks > 0 && a_chunks * 3 < tail) {
+            // the chunks are two thirds empty: a dense list, new chunks (chunk_compact_kernel)
+            SpanGuard g(ctx, BWTS_K_ROUND, 0, 0);
+            chunk_total_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ccount, nchunks, (unsigned long long *)(slots + 3 * CH_SLOT_WORDS), ccount, loff);
+            chunk_compact_kernel<<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, loff, alt_idx, alt_head);
+            { u32 *t = st_idx; st_idx = alt_idx; alt_idx = t; t = st_head; st_head = alt_head; alt_head = t; }
+            S = chunk_nominal_size(a_chunks);
+            const u32 nc = (u32)((a_chunks + S - 1) / S);
+            if (round_trace) fprintf(stderr, "[chunks] list compacted: %llu elements of %llu slots, %u chunks -> %u (nominal chunk %u)\n", (unsigned long long)a_chunks,
+                                     (unsigned long long)tail, nchunks, nc, S);
+            nchunks = nc;
+            chunk_init_kernel<<<dim3((nchunks + 3) / 4), dim3(256), 0, ctx->stream>>>(st_head, 0, a_chunks, S, 0, nchunks, cstart, ccount, mvcount, cwide, wide_possible);
+            CH_HIP(hipGetLastError());
+            tail = a_chunks;
+        }
     }
     if (need_sa) {
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
@@ -1102,7 +1515,14 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         // (a round enqueued behind the stable one has split nothing either: the lists are what they were)
         SpanGuard g(ctx, BWTS_K_EMIT, a_chunks + m_big, 10 * (a_chunks + m_big));
         if (nchunks && a_chunks) {
-            chunk_rest_kernel<<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, prev, out, need_sa ? SA : nullptr);
+            const ChainCtx cx{sp.rank, pinfo, prev, out, need_sa ? SA : nullptr};
+            chunk_rest_records_kernel<<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, mv, mvcount, parking);
+            if (parking) chunk_apply_records_kernel<2><<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(mv, cstart, mvcount, cx, lcount);
+            else chunk_apply_records_kernel<1><<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(mv, cstart, mvcount, cx, lcount);
+            if (parking) {
+                chunk_total_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(ccount, nchunks, (unsigned long long *)slots, lcount, loff);
+                chunk_long_chains_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(mv, cstart, loff, nchunks, cx);
+            }
             CH_HIP(hipGetLastError());
         }
         if (m_big) {
@@ -1110,6 +1530,10 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             DgRestOut rout{bl_idx[blc], bl_head[blc], prev, out, need_sa ? SA : nullptr};
             CH_TRY((device_scan<true, u32>(ctx, m_big, rin, rout, OpMax(), 0u, sp.scan_temp)));
         }
+    }
+    if (parking && out && !prev.P) {
+        chunk_factor_heads_kernel<<<dim3((unsigned)((k + 255) / 256)), dim3(256), 0, ctx->stream>>>(d_T, n, d_fstart, k, sp.rank, out);
+        CH_HIP(hipGetLastError());
     }
     *rounds_io = rounds;
     return BWTS_OK;
