@@ -116,6 +116,10 @@ class _SleepEngine:
 
     inverse_device = forward_device
 
+    def forward_batch(self, arrays):
+        time.sleep(self.delay * len(arrays))
+        return [a.copy() for a in arrays]
+
     def device_equal(self, *a):
         return True
 
@@ -214,6 +218,49 @@ def _pmc_traffic(kernel_prefix, workload, log2n, per_elem=None):
     except Exception:
         pass
     return None, None
+
+
+def _config5_leg(ctx, rank, n, items, workload, barrier, selftest):
+    """BASELINE config 5's real data flow on this rank's GPU: `items` input files of n bytes in tmpfs, mmapped (the CLIs' map_in),
+    through bwts_forward_batch (copies of the neighbouring items overlapped with the transform) into fresh host buffers.  Timed between
+    two barriers; the caller takes the max over ranks.  Returns (seconds, info).  What limits it on a full node is what SURVEY 8(e)
+    predicts: page-cache / mmap and PCIe traffic of all ranks at once, not the GPUs."""
+    import numpy as np
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    td = tempfile.mkdtemp(prefix="bwts_c5_r%d_" % rank, dir=base)
+    try:
+        paths = []
+        if selftest:
+            for i in range(items):
+                p = os.path.join(td, "in%d.bin" % i)
+                np.zeros(min(n, 1 << 16), dtype=np.uint8).tofile(p)
+                paths.append(p)
+        else:
+            tmp = ctx.alloc(n)
+            for i in range(items):
+                ctx.generate(workload, 1 + rank * items + i, n, tmp)
+                p = os.path.join(td, "in%d.bin" % i)
+                tmp.download().tofile(p)
+                paths.append(p)
+            tmp.free()
+        maps = [np.memmap(p, dtype=np.uint8, mode="r") for p in paths]
+        if not selftest:
+            ctx.forward_batch([maps[0][: min(n, 1 << 24)]] * 2)        # warm: the batch's staging rings, workers, second pair of device buffers
+        barrier()
+        t0 = time.perf_counter()
+        outs = ctx.forward_batch(maps)
+        barrier()
+        dt = time.perf_counter() - t0
+        ok = True
+        if not selftest:
+            back = ctx.inverse(outs[0])                                 # one item checked per rank (outside the timed region)
+            ok = bool(np.array_equal(back, maps[0]))
+        info = {"items_per_gpu": items, "bytes_each": int(maps[0].size), "files": "tmpfs (%s), mmapped read-only" % (base or td),
+                "outputs": "fresh (untouched) host buffers allocated inside the call", "first_item_roundtrip_exact": ok}
+        del maps, outs
+        return dt, info
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
 
 
 LINE_FILL_CEILING = 54e9       # random 128-byte line fills per second this chip sustains (tools/micro/random_read.hip, DESIGN.md section 4)
@@ -349,6 +396,8 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer / CLI leg")
     ap.add_argument("--no-text", action="store_true", help="skip the text workload reported beside the headline one")
+    ap.add_argument("--config5-items", type=int, default=4, help="files per GPU in the host-path leg of an N > 1 run (BASELINE config 5); 0 = skip")
+    ap.add_argument("--config5-leg", action="store_true", help="run that leg at N = 1 too")
     ap.add_argument("--selftest-sleep-ms", type=float, default=0.0,
                     help="harness self-test (tests/test_dist_cpu.py): no GPU, no transform; every step sleeps "
                          "(rank+1) x this many ms so the rank/barrier/max-reduce/aggregate logic runs under gloo")
@@ -450,10 +499,16 @@ def main(argv=None):
                 "main": main_agg, "inv_main": inv_main, "agg": agg, "inv_agg": inv_agg}
 
     m = measure(args.workload, args.steps, args.warmup, args.inverse_steps, args.breakdown_steps)
-    times = torch.tensor([m["fwd_s"], m["inv_s"], 0.0 if m["roundtrip"] else 1.0], dtype=torch.float64, device=dev)
+    # N > 1: the leg that measures config 5's real data flow (files in tmpfs -> bwts_forward_batch -> host buffers), every rank at once
+    c5_s, c5_info = 0.0, None
+    if (n_gpus > 1 or args.config5_leg) and args.config5_items > 0:
+        c5_s, c5_info = _config5_leg(ctx, rank, n, args.config5_items, args.workload, barrier, selftest)
+        if not c5_info["first_item_roundtrip_exact"]:
+            m["roundtrip"] = False
+    times = torch.tensor([m["fwd_s"], m["inv_s"], 0.0 if m["roundtrip"] else 1.0, c5_s], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    fwd_s, inv_s, bad = [float(v) for v in times.tolist()]
+    fwd_s, inv_s, bad, c5_s = [float(v) for v in times.tolist()]
 
     rc = 0
     if rank == 0:
@@ -511,6 +566,11 @@ def main(argv=None):
                 rw["line_fill_frac"] = round(fills / LINE_FILL_CEILING, 3)
                 rw["traffic_over_algorithmic"] = round(wt / max(rw["alg_bytes_per_launch"], 1), 1)
             line["roofline_inverse"] = rw
+        if c5_info is not None:
+            # whole job: every rank's files over the slowest rank's wall time (value stays the HBM-resident rate the contract names)
+            c5_bytes = n_gpus * c5_info["items_per_gpu"] * c5_info["bytes_each"]
+            line["config5_host_path"] = dict(c5_info, wall_ms=round(1e3 * c5_s, 2), aggregate_MBps=round(c5_bytes / 1e6 / c5_s, 3),
+                                             what="per rank: files -> mmap -> bwts_forward_batch -> host buffers, all ranks at once, barrier to barrier, max over ranks")
         if selftest:
             line["data"] = "selftest (no transform executed)"
         if n_gpus == 1 and not selftest:

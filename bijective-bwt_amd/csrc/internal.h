@@ -117,6 +117,7 @@ struct bwts_ctx {
     // select alternate code paths -- what the test suite drives -- only when BWTS_TEST_KNOBS=1 is set
     std::vector<std::pair<std::string, std::string>> knobs;
     int fused_scan_cap;    // workgroups of radix_column_scan_fused_kernel that are certain to be resident together (0 = not yet asked)
+    int chain_cap;         // ... of the chained packed pass kernel (radix.hip, CHAINED passes)
     int rx_config;         // radix tile shape (BWTS_RX_CONFIG, a tuning knob; 0 = the product shape)
 
     bwts_timings tm;

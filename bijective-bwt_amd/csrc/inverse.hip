@@ -1006,7 +1006,6 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     if (moments) HIPC(hipMemsetAsync(mom, 0, 3 * mom_classes * sizeof(u64), ctx->stream));
     {
         SpanGuard sg(ctx, BWTS_K_WALK, n, 6 * n);
-        const bool syms16 = [ctx] { const char *e = bwts_knob(ctx, "BWTS_WALK_SYMS"); return e && atoi(e) == 16; }();      // 16-byte symbol stores (A/B against the 64-byte ones)
         if (moments) {
             BWTS_TRY(ensure_dyn_lds(ctx, (const void *)walk_record_kernel<MARK_MOMENTS>, (size_t)MOM_MAX_BUCKETS * 20));
             walk_record_kernel<MARK_MOMENTS><<<dim3(wblocks), dim3(256), (size_t)mom_classes * 20, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
@@ -1018,9 +1017,6 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
         else if (mark == MARK_SENTINEL)
             walk_record_kernel<MARK_SENTINEL><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
                                                                                            ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
-        else if (syms16)
-            walk_record_kernel<MARK_LOG, 4><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
-                                                                                         ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);
         else
             walk_record_kernel<MARK_LOG><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(LF, marks, idxlog, s, node_cap, g, slot, dC, seg, noderec,
                                                                                       ticket, ticket + 3, ticket + 4, ticket + 5, chunk_fill, log_chunks, nbuckets, bucket_seen);

@@ -351,6 +351,80 @@ __global__ __launch_bounds__(512) void radix_hist_packed_kernel(const T *__restr
     }
 }
 
+// ---- CHAINED passes: no per-tile histogram sweep, no column scan --------------------------------------------------------------
+// A pass needs, per tile and digit, the number of elements with that digit in all EARLIER tiles.  The classic pass gets it from a
+// histogram sweep over the pass's input (4 or 2 bytes per element) and a column scan of the [tile][digit] table; five such sweeps
+// cost 3.6 of a 35.6 ms forward at n = 2^30.  The chained pass computes it while it runs (decoupled look-back, Merrill & Garland):
+// the digit totals of ALL passes come from ONE sweep over the keys before the first pass (the multiset of keys never changes), a
+// tile publishes its own digit counts as soon as it has ranked its elements (AGGREGATE), adds up its predecessors' counts walking
+// backwards until it meets one that already knows its inclusive prefix, and publishes its own inclusive prefix (INCLUSIVE).
+//   state word (u64, one per tile and digit): flag (0 nothing, 1 aggregate, 2 inclusive) << 62 | pass tag (1..7) << 59 | value (40 bits);
+//   cleared once per sort, the tag tells the passes apart.
+// Order and progress: a workgroup takes a TICKET when it starts (one counter per pass) and the ticket picks the tile, so a tile only
+// ever waits for tiles whose workgroups have started or are among the next 63 to start -- 64 workgroups are always resident
+// together (checked against the occupancy API once per context), so every wait ends; every spin is bounded all the same and a
+// bound that is hit raises an error word instead of hanging the GPU.  Inside a group of 64 consecutive tickets the tiles are dealt so
+// that ticket t (XCD t % 8 when workgroups start in dispatch order) gets eight CONSECUTIVE tiles' worth of neighbours: seam
+// cache lines between consecutive tiles' runs are still written through one L2 (rx_tile_of_block's reason), seven times out of eight.
+#define RXC_FLAG_AGG   1ull
+#define RXC_FLAG_INCL  2ull
+#define RXC_VALUE_MASK ((1ull << 40) - 1ull)
+#define RXC_SPIN_MAX   (1u << 20)
+#define RXC_GROUP      64u
+#define RXC_RUN        8u
+struct ChainIO {
+    u64 *state;                  // [tiles][256]
+    unsigned int *ticket;        // [8] one per pass; [7] = error word
+    const u64 *gbase;            // [passes][256] exclusive digit totals of the pass
+    u32 tag;                     // 1 + pass
+};
+__device__ __forceinline__ u64 rxc_word(u64 flag, u32 tag, u64 value) { return (flag << 62) | ((u64)tag << 59) | value; }
+
+// digit totals of all passes in one sweep: keys as keybuild leaves them (lo: bits 0..31, c: key bits 32..39 in the low byte when HI16)
+template <bool HI16>
+__global__ __launch_bounds__(512) void radix_global_hist_kernel(const u32 *__restrict__ lo, const u16 *__restrict__ c, u64 m, int passes, unsigned long long *__restrict__ gh)
+{
+    constexpr int NP = 5;
+    __shared__ u32 bins[NP][256];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NP * 256; i += 512) ((u32 *)bins)[i] = 0;
+    __syncthreads();
+    const u64 per = 512ull * 8;
+    for (u64 base = (u64)blockIdx.x * per; base < m; base += (u64)gridDim.x * per) {
+        u32 k[8]; u32 h[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u64 i = base + (u64)j * 512 + tid;
+            k[j] = i < m ? lo[i] : 0u;
+            h[j] = (HI16 && i < m) ? (u32)c[i] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u64 i = base + (u64)j * 512 + tid;
+            if (i < m) {
+                atomicAdd(&bins[0][k[j] & 255u], 1u);
+                atomicAdd(&bins[1][(k[j] >> 8) & 255u], 1u);
+                atomicAdd(&bins[2][(k[j] >> 16) & 255u], 1u);
+                if (passes > 3) atomicAdd(&bins[3][k[j] >> 24], 1u);
+                if (HI16) atomicAdd(&bins[4][h[j] & 255u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < passes * 256; i += 512) { const u32 v = ((u32 *)bins)[i]; if (v) atomicAdd(&gh[i], (unsigned long long)v); }
+}
+// gh[p][d] -> exclusive sums over d, in place (one workgroup of 256 threads per pass)
+__global__ __launch_bounds__(256) void radix_global_base_kernel(unsigned long long *__restrict__ gh)
+{
+    __shared__ u64 sm[4];
+    const int d = threadIdx.x;
+    unsigned long long *row = gh + (size_t)blockIdx.x * 256;
+    const u64 v = row[d];
+    u64 tot;
+    const u64 exc = block_scan_exclusive<u64, OpAdd, 4>(v, OpAdd(), (u64)0, sm, &tot);
+    row[d] = exc;
+}
+
 struct PackedIO {
     const u32 *lo_in; const void *c_in;                    // c: u16 if HI16 else u8
     const u32 *val_in;                                     // not read by the first pass (value = index)
@@ -359,8 +433,8 @@ struct PackedIO {
     u32 *val_out;
 };
 
-template <bool FIRST, bool OUT_WIDE, bool HI16>
-__global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO io, const u32 *__restrict__ tile_off, u64 m, int shift)
+template <bool FIRST, bool OUT_WIDE, bool HI16, bool CHAIN = false>
+__global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO io, const u32 *__restrict__ tile_off, u64 m, int shift, ChainIO ch)
 {
     constexpr int RX_THREADS = 512, RX_ITEMS = 16, RX_WAVES = 8, RX_TILE = 8192;
     extern __shared__ __attribute__((aligned(16))) char rx_smem[];
@@ -372,9 +446,17 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
     u8 *sdig = (u8 *)(whist + RX_WAVES);                           // RX_TILE: digit of the element in slot s
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const u64 tile = rx_tile_of_block((m + RX_TILE - 1) / RX_TILE);
+    u64 tile;
+    if (CHAIN) {
+        // the ticket picks the tile (see CHAINED passes): tickets of a group of 64 are dealt 8 x 8
+        __shared__ u32 s_ticket;
+        if (tid == 0) s_ticket = atomicAdd(&ch.ticket[ch.tag - 1u], 1u);
+        __syncthreads();
+        const u32 b = s_ticket, r = b % RXC_GROUP;
+        tile = (u64)(b - r) + (u64)(r % RXC_RUN) * (RXC_GROUP / RXC_RUN) + (u64)(r / RXC_RUN);
+    } else tile = rx_tile_of_block((m + RX_TILE - 1) / RX_TILE);
     const u64 tile_base = tile * RX_TILE;
-    if (tile_base >= m) return;                                   // padding block of the XCD-aligned grid
+    if (tile_base >= m) return;                                   // padding block of the grid
     const u64 wave_base = tile_base + (u64)w * (64 * RX_ITEMS);
     const u64 remain = m - tile_base;
     const u32 tile_count = remain < RX_TILE ? (u32)remain : (u32)RX_TILE;
@@ -421,6 +503,7 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     __syncthreads();
+    u32 crun = 0, cexc = 0;              // (CHAIN) this tile's count of digit `tid` and the tile-local exclusive prefix over the digits
     {
         u32 run = 0;
         if (tid < 256) {
@@ -435,7 +518,13 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
         const u32 exc = block_scan_exclusive<u32, OpAdd, RX_WAVES>(run, OpAdd(), 0u, scan_sm, &total);
         if (tid < 256) {
             dbase[tid] = exc;
-            gbase[tid] = tile_off[tile * 256 + tid] - exc;
+            if (CHAIN) {
+                // this tile's count of digit `tid`: out at once (the first tile knows its inclusive prefix already); the look-back
+                // itself waits until the first LDS trip has been staged and the other streams' loads are in flight (below)
+                crun = run; cexc = exc;
+                __hip_atomic_store(&ch.state[tile * 256 + tid], rxc_word(tile == 0 ? RXC_FLAG_INCL : RXC_FLAG_AGG, ch.tag, (u64)run), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            } else gbase[tid] = tile_off[tile * 256 + tid] - exc;
         }
     }
     __syncthreads();
@@ -480,6 +569,39 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
             if (DIG_C) sb[j] = PK_VALID(j) ? valp[j * 64] : 0u;
             else sb[j] = PK_VALID(j) ? (HI16 ? (u32)c16[j * 64] : (u32)c8[j * 64]) : 0u;
         }
+    }
+    if (CHAIN && tid < 256) {
+        // look-back: thread `tid` adds up digit tid's counts of the tiles before this one, nearest first, four state words in flight
+        u64 prefix = 0;
+        if (tile != 0) {
+            u64 p = tile;                                    // tiles p - 1, p - 2, ... are looked at next
+            bool done = false;
+            u32 spins = 0;
+            while (!done) {
+                u64 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    v[q] = p > (u64)q ? __hip_atomic_load(&ch.state[(p - 1 - (u64)q) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                int used = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (done || used != q) continue;
+                    if (p <= (u64)q) { done = true; continue; }          // (cannot happen: tile 0 is inclusive)
+                    const u64 x = v[q];
+                    if (((u32)(x >> 59) & 7u) != ch.tag || (x >> 62) == 0ull) continue;      // not there yet: look again from here
+                    prefix += x & RXC_VALUE_MASK;
+                    used = q + 1;
+                    if ((x >> 62) == RXC_FLAG_INCL) done = true;
+                }
+                p -= (u64)used;
+                if (!done && used == 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > RXC_SPIN_MAX) { __hip_atomic_store(&ch.ticket[7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); done = true; }
+                }
+            }
+            __hip_atomic_store(&ch.state[tile * 256 + tid], rxc_word(RXC_FLAG_INCL, ch.tag, prefix + (u64)crun), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        gbase[tid] = (u32)(ch.gbase[(ch.tag - 1u) * 256 + tid] + prefix) - cexc;
     }
     __syncthreads();
     u32 hi_s[DIG_C ? RX_ITEMS : 1];                                // last 40-bit pass: the slot's key byte waits for its lo
@@ -556,13 +678,38 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
 #undef PK_VALID
 }
 
+#define RX_PACKED_LDS ((size_t)8192 * 9 + 2048 + 64 + (size_t)8 * 512)
 template <bool FIRST, bool OUT_WIDE, bool HI16>
-static int launch_scatter_packed(bwts_ctx *ctx, u64 tiles, const PackedIO &io, const u32 *tile_off, u64 m, int shift)
+static int launch_scatter_packed(bwts_ctx *ctx, u64 tiles, const PackedIO &io, const u32 *tile_off, u64 m, int shift, const ChainIO *ch = nullptr)
 {
-    constexpr size_t lds = (size_t)8192 * 9 + 2048 + 64 + (size_t)8 * 512;
+    constexpr size_t lds = RX_PACKED_LDS;
+    if (ch) {
+        BWTS_TRY(ensure_dyn_lds(ctx, (const void *)radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16, true>, lds));
+        const u64 grid = (tiles + RXC_GROUP - 1) / RXC_GROUP * RXC_GROUP;
+        radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16, true><<<dim3((unsigned)grid), dim3(512), lds, ctx->stream>>>(io, tile_off, m, shift, *ch);
+        return BWTS_OK;
+    }
     BWTS_TRY(ensure_dyn_lds(ctx, (const void *)radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16>, lds));
-    radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16><<<dim3((unsigned)rx_grid(tiles)), dim3(512), lds, ctx->stream>>>(io, tile_off, m, shift);
+    radix_scatter_packed_kernel<FIRST, OUT_WIDE, HI16><<<dim3((unsigned)rx_grid(tiles)), dim3(512), lds, ctx->stream>>>(io, tile_off, m, shift, ChainIO{});
     return BWTS_OK;
+}
+
+// may the chained passes be used on this context?  (BWTS_RX_CHAIN=1 asks for them; 64 workgroups of the pass kernel must be resident together -- with a margin)
+static bool radix_chain_ok(bwts_ctx *ctx, u64 m)
+{
+    if (m < (1ull << 22)) return false;             // (small sorts: the classic pass's table work is nothing, and the state words need the room)
+    // (opt-in: exact, but measured slower -- 7.5 against 4.65 ms per pass at n = 2^30, profiles/history/r04_chained_passes.md)
+    { const char *e = bwts_knob(ctx, "BWTS_RX_CHAIN"); if (!(e && atoi(e) == 1)) return false; }
+    if (ctx->chain_cap == 0) {
+        int per_cu = 0, cus = 0;
+        ctx->chain_cap = -1;
+        if (hipFuncSetAttribute((const void *)radix_scatter_packed_kernel<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RX_PACKED_LDS) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, radix_scatter_packed_kernel<false, false, true, true>, 512, RX_PACKED_LDS) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && per_cu > 0 && cus > 0)
+            ctx->chain_cap = per_cu * cus;
+        else (void)hipGetLastError();
+    }
+    return ctx->chain_cap >= 4 * (int)RXC_GROUP;
 }
 
 // round 0 with the byte stream and identity values, keys of 17..40 bits: split -> packed ... packed -> wide
@@ -574,6 +721,22 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
     const size_t lo_bytes = align_up((size_t)m * 4, 256);
     const u64 pass_bytes = HI16 ? 20 : 18;
     int cur = 0;
+    // chained passes (see CHAINED passes above): the state words live where the tile table would, the digit totals and tickets behind them
+    const bool chain = radix_chain_ok(ctx, m);
+    ChainIO ch{};
+    if (chain) {
+        const size_t st_bytes = align_up((size_t)tiles * 256 * sizeof(u64), 256);
+        if (st_bytes + 8 * 256 * sizeof(u64) + 256 > radix_tile_hist_bytes(m)) return BWTS_E_INTERNAL;
+        ch.state = (u64 *)tile_hist;
+        unsigned long long *gh = (unsigned long long *)((char *)tile_hist + st_bytes);
+        ch.gbase = (const u64 *)gh;
+        ch.ticket = (unsigned int *)(gh + 8 * 256);
+        HIPC(hipMemsetAsync(tile_hist, 0, st_bytes + 8 * 256 * sizeof(u64) + 256, ctx->stream));
+        SpanGuard g(ctx, BWTS_K_RADIX_HIST, m, (HI16 ? 6 : 4) * m);
+        radix_global_hist_kernel<HI16><<<dim3(2048), dim3(512), 0, ctx->stream>>>((const u32 *)plan.keys[0], (const u16 *)((char *)plan.keys[0] + lo_bytes), m, passes, gh);
+        radix_global_base_kernel<<<dim3((unsigned)passes), dim3(256), 0, ctx->stream>>>(gh);
+        HIPC(hipGetLastError());
+    }
     for (int p = 0; p < passes; p++) {
         const int shift = 8 * p;
         const bool first = p == 0, last = p == passes - 1;
@@ -582,12 +745,14 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
         io.lo_in = (const u32 *)src; io.c_in = src + lo_bytes; io.val_in = plan.vals[cur];
         io.kout_wide = plan.keys[cur ^ 1]; io.sym_out = plan.sym_final;
         io.lo_out = (u32 *)dst; io.c_out = dst + lo_bytes; io.val_out = plan.vals[cur ^ 1];
-        {
+        ch.tag = (u32)p + 1u;
+        const ChainIO *chp = chain ? &ch : nullptr;
+        if (!chain) {
             SpanGuard g(ctx, BWTS_K_RADIX_HIST, m, ((HI16 && shift >= 32) ? 2 : 4) * m);
             if (HI16 && shift >= 32) radix_hist_packed_kernel<u16><<<dim3((unsigned)tiles), dim3(512), 0, ctx->stream>>>((const u16 *)io.c_in, m, 0, tile_hist);
             else radix_hist_packed_kernel<u32><<<dim3((unsigned)tiles), dim3(512), 0, ctx->stream>>>(io.lo_in, m, shift, tile_hist);
         }
-        {
+        if (!chain) {
             SpanGuard g(ctx, BWTS_K_RADIX_SCAN, tiles * 256, tiles * 256 * 12);
             STAGE("packed pass: histogram");
             BWTS_TRY(radix_column_scan(ctx, tile_hist, tiles, plan.scan_temp));
@@ -595,19 +760,26 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
         }
         if (first) {
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (pass_bytes / 2 - 4 + pass_bytes / 2) * m);
-            BWTS_TRY((launch_scatter_packed<true, false, HI16>(ctx, tiles, io, tile_hist, m, shift)));
+            BWTS_TRY((launch_scatter_packed<true, false, HI16>(ctx, tiles, io, tile_hist, m, shift, chp)));
         } else if (last) {
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, (pass_bytes / 2 + 13) * m);
-            BWTS_TRY((launch_scatter_packed<false, true, HI16>(ctx, tiles, io, tile_hist, m, shift)));
+            BWTS_TRY((launch_scatter_packed<false, true, HI16>(ctx, tiles, io, tile_hist, m, shift, chp)));
         } else {
             // timed a second time under its own class: the roofline kernel (one template variant, n-sized launches)
             SpanGuard g(ctx, BWTS_K_RADIX_SCATTER, m, pass_bytes * m);
             SpanGuard gm(ctx, BWTS_K_RADIX_SCATTER_MAIN, m, pass_bytes * m);
-            BWTS_TRY((launch_scatter_packed<false, false, HI16>(ctx, tiles, io, tile_hist, m, shift)));
+            BWTS_TRY((launch_scatter_packed<false, false, HI16>(ctx, tiles, io, tile_hist, m, shift, chp)));
         }
         HIPC(hipGetLastError());
         STAGE("packed pass: scatter");
         cur ^= 1;
+    }
+    if (chain) {
+        // a look-back that ran into its spin bound has raised the error word: the sort's output is not to be trusted
+        unsigned int err = 0;
+        HIPC(hipMemcpyAsync(&err, ch.ticket + 7, sizeof(err), hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(hipStreamSynchronize(ctx->stream));
+        if (err) return BWTS_E_INTERNAL;
     }
     *result_buf = cur;
     return BWTS_OK;

@@ -31,6 +31,12 @@ def test_world_size_2_gloo():
     expect = 2 * (1 << 20) / 1e6 / (j["ms_per_step"] / 1e3)
     assert abs(j["value"] - expect) / expect < 0.01
     assert j["roundtrip_exact"] is True and "cpu_baseline" not in j
+    # the config-5 leg (files in tmpfs -> batch entry point -> host buffers): 4 items per rank, the slowest rank sleeps 2 x 20 ms per item;
+    # aggregate = all ranks' bytes over the max wall time
+    c5 = j["config5_host_path"]
+    assert c5["items_per_gpu"] == 4 and 160.0 <= c5["wall_ms"] < 400.0
+    expect5 = 2 * 4 * c5["bytes_each"] / 1e6 / (c5["wall_ms"] / 1e3)
+    assert abs(c5["aggregate_MBps"] - expect5) / expect5 < 0.02
 
 
 def test_self_launch_without_outer_torchrun():

@@ -1097,7 +1097,6 @@ def test_smoke_entry():
 # (last in the file: should one of these children die -- DESIGN.md section 9 -- every other test of the suite has run by then)
 @pytest.mark.parametrize("env", [
     {"BWTS_VARLEN": "1", "BWTS_KEY_BITS": "24"},      # variable-length key codes on every input, narrow keys: many ties, sparse ranks
-    {"BWTS_VARLEN": "1", "BWTS_KEY_BITS": "64"},
     {"BWTS_VARLEN": "0", "BWTS_KEY_SYMBOLS": "2"},    # fixed-width keys of two symbols: nearly everything tied, dense ranks
     {"BWTS_LYNDON": "general"},                       # factors from a full suffix sort + prefix minima of ISA
     {"BWTS_EMIT": "gather"},                          # classic bwts[r] = P[sa[r]] gather instead of the carried byte
@@ -1106,21 +1105,16 @@ def test_smoke_entry():
     {"BWTS_RANKBUILD": "plain"},
     {"BWTS_DENSE": "tiles", "BWTS_DENSE_RUNS": "1"},  # (tile form) activation rounds from the run structure of the position-ordered list (opt-in)
     {"BWTS_DENSE_STEP": "2"},                         # group-local rounds with plain doubling (one successor rank) instead of the quadrupled step
-    {"BWTS_DENSE": "tiles", "BWTS_DENSE_STEP": "2"},
     {"BWTS_DENSE": "tiles"},                          # the tile form of the group-local rounds (round 2) instead of the chunked one
-    {"BWTS_DENSE": "tiles", "BWTS_DENSE_ORDER": "0"}, # ... and without ordering the list by position
-    {"BWTS_DENSE": "legacy"},                         # later rounds with many ties: list in SA order, radix-sorted, instead of the group-local rounds
-    {"BWTS_DENSE": "legacy", "BWTS_SEGSORT": "0"},                            # later rounds: radix sort of the whole tied list instead of sorting small groups in place
     {"BWTS_RX_SMALL": "0"},                           # small sorts through the multi-launch passes instead of the one-workgroup kernel
+    {"BWTS_RX_CHAIN": "1"},                           # round-0 packed passes with decoupled look-back instead of histogram sweep + column scan (>= 2^22 elements; opt-in: measured slower)
     {"BWTS_RX_FUSED_SCAN": "0"},                      # column scan of the tile table in five launches instead of the fused kernel
-    {"BWTS_WALK_SYMS": "16", "BWTS_INV_MARK": "log"},   # inverse walk with 16-byte symbol stores (a variant of the index-log walk)
     {"BWTS_K0DIR": "0"},                              # sparse key builder: plain binary searches, no directories                      # dense rank array by two plain scatters instead of the binned one
     {"BWTS_INV_MARK": "log"},                         # inverse logs every visited index (the fallback of the per-range moments)
     {"BWTS_INV_MARK": "sentinel"},                    # inverse marks visited entries in place instead of logging them
     {"BWTS_BYTEMARK": "1"},                           # inverse marks in a byte map (the n = 2^32 fallback)
     {"BWTS_SPLIT_LOG2": "0"},                         # inverse: every element a splitter (plain pointer jumping)
     {"BWTS_POISON": "1"},                             # every arena / side block filled with 0xA5 before use: nothing may read what nothing wrote
-    {"BWTS_POISON": "1", "BWTS_DENSE": "tiles"},
     {"BWTS_PARK": "1"},                               # later rounds with PARKED CHAINS (csrc/chunk_rounds.h; opt-in: measured slower than the default rounds)
     {"BWTS_PARK": "1", "BWTS_PARK_STATIC": "1"},      # ... and long repeats parked before the first round from the sorted group records
     {"BWTS_RESERVE_HELPER": "1"},                     # host path: EVERY arena growth through the helper thread (release on the caller with the stream drained, hipMalloc alone on the helper: DESIGN.md section 9)
