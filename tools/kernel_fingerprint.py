@@ -107,6 +107,30 @@ def matching(fps, name_prefix, template_args=None):
     return sorted(hits)
 
 
+def pretty(sym):
+    """name<template arguments> of a mangled kernel symbol, as far as rocprofv3's demangled names need it to be matched: the unqualified
+    name and a template-argument list made of bool / int literals (all the library's kernel templates take are those and types).
+    Returns (name, "<a, b, ...>" or "" when there is no list or it holds something else)."""
+    import re
+    m = re.match(r"_Z(\d+)", sym)
+    if not m:
+        return sym, ""
+    ln = int(m.group(1))
+    name = sym[m.end():m.end() + ln]
+    rest = sym[m.end() + ln:]
+    if not rest.startswith("I"):
+        return name, ""
+    args, i = [], 1
+    while i < len(rest) and rest[i] != "E":
+        mm = re.match(r"L([bijlmxy])(n?)(\d+)E", rest[i:])
+        if not mm:
+            return name, ""
+        v = mm.group(3)
+        args.append(("true" if v != "0" else "false") if mm.group(1) == "b" else ("-" if mm.group(2) else "") + v + ("u" if mm.group(1) in "jmy" else ""))
+        i += mm.end()
+    return name, "<" + ", ".join(args) + ">"
+
+
 def combined(fps, symbols):
     """One hash for a set of kernels (a record that sums several kernels' traffic)."""
     h = hashlib.sha256()
