@@ -1235,28 +1235,19 @@ int inverse_device_impl(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out)
     // beyond 32-bit indices: the 64-bit form (wide_inverse.h); BWTS_FORCE_WIDE sends every input there (tests)
     const int force_wide = [ctx] { const char *e = bwts_knob(ctx, "BWTS_FORCE_WIDE"); return e ? atoi(e) : 0; }();
     ctx->tm.attempts = 1;
-    if (n > 0x100000000ull || force_wide) return inverse_wide_impl(ctx, d_in, n, d_out);
     if (n > 0x80000000ull) {
         // one byte value only: LF is the identity, n cycles of one element, the text is the input (unbwts.c:66-86 walks each of them
         // in one step).  The general route holds ~110 bytes per element of cycles that meet no splitter -- all of them here --, which
         // beyond 2^31 elements no device has; so large inputs are looked at first (eight probes, then the histogram only if they agree).
-        u8 probe[8];
-        for (int i = 0; i < 8; i++) HIPC(hipMemcpyAsync(&probe[i], d_in + (n - 1) / 7 * (u64)i, 1, hipMemcpyDeviceToHost, ctx->stream));
-        HIPC(hipStreamSynchronize(ctx->stream));
-        bool same = true;
-        for (int i = 1; i < 8; i++) same = same && probe[i] == probe[0];
-        if (same) {
-            BWTS_TRY(byte_histogram_device(ctx, d_in, n, ctx->d_small));
-            BWTS_TRY(read_small(ctx, 0, 256));
-            int present = 0;
-            for (int c = 0; c < 256; c++) present += ctx->h_small[c] ? 1 : 0;
-            if (present == 1) {
-                HIPC(hipMemcpyAsync(d_out, d_in, n, hipMemcpyDeviceToDevice, ctx->stream));
-                ctx->tm.factors = n; ctx->tm.unvisited = 0;
-                return BWTS_OK;
-            }
+        bool constant = false;
+        BWTS_TRY(constant_input_probe(ctx, d_in, n, &constant));
+        if (constant) {
+            HIPC(hipMemcpyAsync(d_out, d_in, n, hipMemcpyDefault, ctx->stream));
+            ctx->tm.factors = n; ctx->tm.unvisited = 0;
+            return BWTS_OK;
         }
     }
+    if (n > 0x100000000ull || force_wide) return inverse_wide_impl(ctx, d_in, n, d_out);
     bool retry = false, ambiguous = false;
     // how the unreached elements are found: per-range moments (default; falls back to the index log when too many are missing),
     // the index log, or the two mark forms (BWTS_INV_MARK=log|sentinel|bytemap, BWTS_BYTEMARK=1: tests, and the fallback chain below)

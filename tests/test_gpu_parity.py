@@ -463,19 +463,21 @@ def test_constant_input_at_2p32(ctx):
     for m in (1, 7, 100000):
         x = np.full(m, 200, dtype=np.uint8)
         assert np.array_equal(ctx.forward(x), O.forward(x)) and np.array_equal(ctx.inverse(x), x)
-    n = 1 << 32
-    x = np.full(n, 97, dtype=np.uint8)
-    d_in, d_out = ctx.alloc(n), ctx.alloc(n)
-    try:
-        d_in.upload(x)
-        ctx.forward_device(d_in, n, d_out)
-        assert ctx.timings().factors == n
-        assert ctx.device_equal(d_in, d_out, n)
-        ctx.inverse_device(d_in, n, d_out)
-        assert ctx.device_equal(d_in, d_out, n)
-    finally:
-        d_in.free()
-        d_out.free()
+    # ... and just beyond 2^32, where the 64-bit paths would refuse it (2^32 + 4097 factor candidates: BWTS_E_RANGE before round 4)
+    for n in (1 << 32, (1 << 32) + 4097):
+        x = np.full(n, 97, dtype=np.uint8)
+        d_in, d_out = ctx.alloc(n), ctx.alloc(n)
+        try:
+            d_in.upload(x)
+            del x
+            ctx.forward_device(d_in, n, d_out)
+            assert ctx.timings().factors == n
+            assert ctx.device_equal(d_in, d_out, n)
+            ctx.inverse_device(d_in, n, d_out)
+            assert ctx.device_equal(d_in, d_out, n)
+        finally:
+            d_in.free()
+            d_out.free()
 
 
 def test_config4_dna_4GiB_properties(ctx, pkg):
