@@ -755,12 +755,7 @@ __global__ __launch_bounds__(256) void tpos_directory_kernel(const u32 *__restri
     }
     pdir[k] = (u32)lo;
 }
-// the sorted round-0 keys: u64, or split as the packed passes' last pass leaves them (SortPlan::out_split)
-struct SortedKeys {
-    const u64 *wide; const u32 *lo; const u8 *hi;
-    __device__ __forceinline__ u64 operator[](u64 i) const { return wide ? wide[i] : ((u64)lo[i] | (hi ? (u64)hi[i] << 32 : 0ull)); }
-};
-__global__ __launch_bounds__(256) void k0_directory_kernel(const SortedKeys K0, u64 n, int key_bits, int dlog, u64 *__restrict__ dir)
+__global__ __launch_bounds__(256) void k0_directory_kernel(const u64 *__restrict__ K0, u64 n, int key_bits, int dlog, u64 *__restrict__ dir)
 {
     const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
     if (k > (1ull << dlog)) return;
@@ -773,7 +768,7 @@ __global__ __launch_bounds__(256) void k0_directory_kernel(const SortedKeys K0, 
     }
     dir[k] = lo;
 }
-__device__ __forceinline__ u64 k0_lower_bound(const SortedKeys &K0, u64 n, u64 want, const u64 *__restrict__ dir, int dlog, int key_bits)
+__device__ __forceinline__ u64 k0_lower_bound(const u64 *__restrict__ K0, u64 n, u64 want, const u64 *__restrict__ dir, int dlog, int key_bits)
 {
     u64 lo = 0, hi = n;
     if (dir) {
@@ -814,7 +809,7 @@ __device__ __forceinline__ u64 k0_lower_bound(const SortedKeys &K0, u64 n, u64 w
 template <bool CYCLIC>
 __global__ __launch_bounds__(256) void keybuild_sparse_kernel(const u32 *__restrict__ a_idx, const u32 *__restrict__ a_head, u64 a,
                                                               const u8 *__restrict__ T, u64 n, const u8 *__restrict__ codes,
-                                                              int bits, int msym, int pad_add, u64 h, const SortedKeys K0, int rb,
+                                                              int bits, int msym, int pad_add, u64 h, const u64 *__restrict__ K0, int rb,
                                                               const u32 *__restrict__ fstart, u64 k, u64 *__restrict__ keys,
                                                               const u64 *__restrict__ vtab /* variable-length codes, or null */, int key_bits,
                                                               const u32 *__restrict__ tpos, const u32 *__restrict__ trank, u64 a0,
@@ -974,8 +969,7 @@ struct GroupOut {
 // from __ballot); the scan then runs over n/64 words instead of n elements, and tied_from_flags_kernel turns the set
 // bits into the tied list.  Same outputs as GroupIn/GroupOut with rb < 0, a third of the time.
 #define GF_WORDS 8      // words (of 64 slots) a wave handles per step: eight key loads in flight per lane
-template <bool SPLIT /* the keys come as SortedKeys' split form */>
-__global__ __launch_bounds__(256) void group_flags_kernel(const SortedKeys KS, u64 n, u64 *__restrict__ headw, u64 *__restrict__ keepw,
+__global__ __launch_bounds__(256) void group_flags_kernel(const u64 *__restrict__ K, u64 n, u64 *__restrict__ headw, u64 *__restrict__ keepw,
                                                           u64 mask = ~0ull /* key bits that count (the 64-bit path parks position bits above them) */)
 {
     const int lane = lane_id();
@@ -986,17 +980,12 @@ __global__ __launch_bounds__(256) void group_flags_kernel(const SortedKeys KS, u
 #pragma unroll
         for (int q = 0; q < GF_WORDS; q++) {
             const u64 i = (w0 + q) * 64 + lane;
-            if (SPLIT) {
-                // (both streams' loads of all eight words issued before anything is combined)
-                const u32 l = i < n ? KS.lo[i] : 0u;
-                const u32 hh = (i < n && KS.hi) ? (u32)KS.hi[i] : 0u;
-                k[q] = ((u64)l | ((u64)hh << 32)) & mask;
-            } else k[q] = i < n ? KS.wide[i] & mask : 0;
+            k[q] = i < n ? K[i] & mask : 0;
         }
         const u64 first = w0 * 64, last = (w0 + GF_WORDS) * 64 - 1;      // the chunk's outer neighbours
         u64 edge = 0;
-        if (lane == 0 && first > 0) edge = KS[first - 1] & mask;
-        if (lane == 63 && last + 1 < n) edge = KS[last + 1] & mask;
+        if (lane == 0 && first > 0) edge = K[first - 1] & mask;
+        if (lane == 63 && last + 1 < n) edge = K[last + 1] & mask;
         u64 mine_h = 0, mine_k = 0;
 #pragma unroll
         for (int q = 0; q < GF_WORDS; q++) {
@@ -1379,10 +1368,6 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     plan.sym_src = sp.carry_src; plan.sym_buf[0] = sp.carry_buf[0]; plan.sym_buf[1] = sp.carry_buf[1]; plan.sym_final = sp.carry_out;
     plan.vals_identity = radix_supports_sym(ctx);     // keybuild0 writes no value array
     plan.keys_split = CYCLIC && sp.split_keys && plan.sym_final && plan.vals_identity;
-    const bool scan_by_keys = [ctx] { const char *e = bwts_knob(ctx, "BWTS_GROUPSCAN"); return e && !strcmp(e, "keys"); }();
-    // the packed passes leave the sorted keys split (5 bytes per key written and read again instead of 8) for everything that
-    // reads them below: the group flags, the sparse rank searches and their directory (the element-wise test scan wants u64)
-    plan.out_split = plan.keys_split && !scan_by_keys && radix_packed_applicable(ctx, n, al.key_bits);
     if (CYCLIC && sp.split_keys && !plan.keys_split) return BWTS_E_INTERNAL;      // keybuild split the keys for a sort that cannot take them
     if (!plan.vals_identity) {                     // tuning configs without the identity variant: materialise it
         u64 blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
@@ -1393,8 +1378,6 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     BWTS_TRY(radix_sort_pairs(ctx, plan, n, al.key_bits, &res));
     STAGE("round-0 sort");
     u64 *K0 = sp.keys[res];
-    const SortedKeys K0v = plan.out_split ? SortedKeys{nullptr, (const u32 *)K0, al.key_bits > 32 ? (const u8 *)K0 + align_up((size_t)n * 4, 256) : nullptr}
-                                          : SortedKeys{K0, nullptr, nullptr};
     u32 *SA = sp.vals[res];
     // the other key buffer (8n bytes) and value buffer (4n) are free: first active list goes there
     ActiveList cur;
@@ -1407,6 +1390,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
     const u64 *flag_heads_any = nullptr, *flag_pre_any = nullptr, *flag_keep = nullptr;   // the flag words wherever they live
     u64 flag_words = 0;
     bool rank_early = false;                                  // the dense rank array was built before the tied list
+    const bool scan_by_keys = [ctx] { const char *e = bwts_knob(ctx, "BWTS_GROUPSCAN"); return e && !strcmp(e, "keys"); }();
     if (scan_by_keys) {             // the element-wise scan the later rounds use (kept selectable for tests)
         SpanGuard g(ctx, BWTS_K_RERANK, n, 8 * n);
         GroupIn in{K0, nullptr, n, -1};
@@ -1427,8 +1411,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
         }
         u64 waves = (words + GF_WORDS - 1) / GF_WORDS;
         unsigned blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
-        if (plan.out_split) group_flags_kernel<true><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(K0v, n, headw, keepw);
-        else group_flags_kernel<false><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(K0v, n, headw, keepw);
+        group_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(K0, n, headw, keepw);
         WordIn in{headw, keepw};
         ScanStoreArr<u64> out{pre};
         BWTS_TRY((device_scan<false, u64>(ctx, words, in, out, OpHeadCount(), (u64)0, sp.scan_temp)));
@@ -1522,7 +1505,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
             if (dlog > bitlen_u64(n)) dlog = bitlen_u64(n);
             if (!no_dir && dlog >= 8) {
                 dir = (u64 *)(base + 2 * e8 + 9 * e4);
-                k0_directory_kernel<<<dim3((unsigned)(((1ull << dlog) + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(K0v, n, kb, dlog, dir);
+                k0_directory_kernel<<<dim3((unsigned)(((1ull << dlog) + 1 + 255) / 256)), dim3(256), 0, ctx->stream>>>(K0, n, kb, dlog, dir);
             }
             tied_map_keys_kernel<<<dim3((unsigned)((a + 255) / 256)), dim3(256), 0, ctx->stream>>>(cur.idx, a, akeys[0]);
             HIPC(hipMemcpyAsync(scratch, cur.head, a * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1587,7 +1570,7 @@ static int doubling_sort(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al
                 SpanGuard g(ctx, BWTS_K_KEYBUILD, a, 20 * a);
                 const unsigned blocks = (unsigned)((a + 255) / 256);
                 keybuild_sparse_kernel<CYCLIC><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(
-                    cur.idx, cur.head, a, d_T, n, d_codes, al.bits, al.msym, al.pad_add, h, K0v, rb, d_fstart, k, akeys[0],
+                    cur.idx, cur.head, a, d_T, n, d_codes, al.bits, al.msym, al.pad_add, h, K0, rb, d_fstart, k, akeys[0],
                     al.varlen ? ctx->d_small + SM_VTAB : nullptr, al.key_bits, tpos, trank, a0, dir, dlog, pdir, psh);
                 HIPC(hipGetLastError());
             }

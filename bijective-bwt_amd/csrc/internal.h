@@ -198,9 +198,6 @@ struct SortPlan {
     // (u8 *)keys[0] + align_up(4 m, 256) the c stream: u16 (key bits 32..39 | carried byte << 8) for keys of more than 32
     // bits, else u8 (the carried byte).  sym_src is not read; needs sym_final and vals_identity.
     bool keys_split = false;
-    // (with keys_split) the last pass leaves the SORTED keys split too -- u32 low words at keys[result], key byte 4 (keys of more than
-    // 32 bits) as u8 at (u8 *)keys[result] + align_up(4 m, 256) -- instead of u64: 5 bytes written and read again instead of 8
-    bool out_split = false;
 };
 bool radix_packed_applicable(const bwts_ctx *ctx, u64 m, int key_bits);   // will radix_sort_pairs run its packed-stream passes for such a sort?
 bool radix_supports_sym(const bwts_ctx *ctx);       // the byte stream is compiled for the default tile shape only

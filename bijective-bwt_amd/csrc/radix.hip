@@ -429,7 +429,6 @@ struct PackedIO {
     const u32 *lo_in; const void *c_in;                    // c: u16 if HI16 else u8
     const u32 *val_in;                                     // not read by the first pass (value = index)
     u64 *kout_wide; u8 *sym_out;                           // OUT_WIDE
-    u32 *klo_out; u8 *khi_out;                             // OUT_WIDE, sorted keys left SPLIT (klo_out != null): low 32 bits and key byte 4 -- 5 bytes instead of 8
     u32 *lo_out; void *c_out;                              // !OUT_WIDE
     u32 *val_out;
 };
@@ -625,7 +624,7 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
             if (s < tile_count) {
                 const u32 dst = g[jj] + s;
                 if (DIG_C) io.sym_out[dst] = (u8)(x[jj] >> 8);
-                else if (OUT_WIDE) { if (io.klo_out) io.klo_out[dst] = x[jj]; else io.kout_wide[dst] = (u64)x[jj]; }
+                else if (OUT_WIDE) io.kout_wide[dst] = (u64)x[jj];
                 else io.lo_out[dst] = x[jj];
             }
         }
@@ -662,8 +661,7 @@ __global__ __launch_bounds__(512, 4) void radix_scatter_packed_kernel(PackedIO i
             if (s < tile_count) {
                 const u32 dst = g[jj] + s;
                 if (DIG_C) {
-                    if (io.klo_out) { io.klo_out[dst] = e[jj].x; io.khi_out[dst] = (u8)hi_s[j0 + jj]; }
-                    else io.kout_wide[dst] = (u64)e[jj].x | ((u64)hi_s[j0 + jj] << 32);
+                    io.kout_wide[dst] = (u64)e[jj].x | ((u64)hi_s[j0 + jj] << 32);
                     io.val_out[dst] = e[jj].y;
                 } else {
                     io.val_out[dst] = e[jj].x;
@@ -746,7 +744,6 @@ static int radix_sort_packed(bwts_ctx *ctx, const SortPlan &plan, u64 m, int pas
         PackedIO io{};
         io.lo_in = (const u32 *)src; io.c_in = src + lo_bytes; io.val_in = plan.vals[cur];
         io.kout_wide = plan.keys[cur ^ 1]; io.sym_out = plan.sym_final;
-        if (plan.out_split) { io.klo_out = (u32 *)dst; io.khi_out = (u8 *)dst + lo_bytes; }
         io.lo_out = (u32 *)dst; io.c_out = dst + lo_bytes; io.val_out = plan.vals[cur ^ 1];
         ch.tag = (u32)p + 1u;
         const ChainIO *chp = chain ? &ch : nullptr;

@@ -635,7 +635,7 @@ static int forward_wide_run(bwts_ctx *ctx, const u8 *d_T, u64 n, u8 *d_out, bool
             SpanGuard g(ctx, BWTS_K_RERANK, m, 8 * m);
             u64 waves = (words + GF_WORDS - 1) / GF_WORDS;
             unsigned blocks = (unsigned)((waves + 3) / 4 < 16384 ? (waves + 3) / 4 : 16384);
-            group_flags_kernel<false><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(SortedKeys{sp.keys[res], nullptr, nullptr}, m, headw, keepw, carry ? (1ull << WIDE_HI_SHIFT) - 1ull : ~0ull);
+            group_flags_kernel<<<dim3(blocks), dim3(256), 0, ctx->stream>>>(sp.keys[res], m, headw, keepw, carry ? (1ull << WIDE_HI_SHIFT) - 1ull : ~0ull);
             WordIn win{headw, keepw};
             ScanStoreArr<u64> wout{prew};
             BWTS_TRY((device_scan<false, u64>(ctx, words, win, wout, OpHeadCount(), (u64)0, scan_temp)));

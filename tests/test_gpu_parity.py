@@ -1096,8 +1096,8 @@ def test_smoke_entry():
     ge.smoke()
 
 
-# (last in the file: should one of these children die -- DESIGN.md section 9 -- every other test of the suite has run by then)
-@pytest.mark.parametrize("env", [
+# (last in the file: should one of these children die -- DESIGN.md section 10 -- every other test of the suite has run by then)
+_ALT_ENVS = [
     {"BWTS_VARLEN": "1", "BWTS_KEY_BITS": "24"},      # variable-length key codes on every input, narrow keys: many ties, sparse ranks
     {"BWTS_VARLEN": "0", "BWTS_KEY_SYMBOLS": "2"},    # fixed-width keys of two symbols: nearly everything tied, dense ranks
     {"BWTS_LYNDON": "general"},                       # factors from a full suffix sort + prefix minima of ISA
@@ -1120,15 +1120,16 @@ def test_smoke_entry():
     {"BWTS_PARK": "1"},                               # later rounds with PARKED CHAINS (csrc/chunk_rounds.h; opt-in: measured slower than the default rounds)
     {"BWTS_PARK": "1", "BWTS_PARK_STATIC": "1"},      # ... and long repeats parked before the first round from the sorted group records
     {"BWTS_RESERVE_HELPER": "1"},                     # host path: EVERY arena growth through the helper thread (release on the caller with the stream drained, hipMalloc alone on the helper: DESIGN.md section 9)
-], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
-def test_alternate_paths(env):
+]
+_alt_pool = {}
+
+
+def _alt_child(env):
     # (-s: the child must not capture its tests' stderr -- what the HIP runtime says when it aborts the process would stay in the capture file)
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-s",
            "-k", "(small or mid_size or deep_repeats or dense_ties or dense_rounds or chunk_rounds or text_16MiB or reference_unbwts_vectors_through_cabi) and not alternate"]
     # (-k matches case-insensitively and looks at parameter ids too: without the exclusion, an id like BWTS_RX_SMALL=0
     # makes the child select this very test and start a child of its own.)
-    if os.environ.get("BWTS_TEST_CHILD"):
-        pytest.skip("already inside a child run")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                             env=dict(os.environ, BWTS_TEST_CHILD="1", BWTS_TEST_KNOBS="1", LIBC_FATAL_STDERR_="1", BWTS_TRACE_ALLOC="1", **env), cwd=ROOT)
     try:
@@ -1137,4 +1138,19 @@ def test_alternate_paths(env):
         proc.kill()
         out, _ = proc.communicate()
     _wait_gpu_handle_released(proc.pid)
-    assert proc.returncode == 0, _child_report("alternate_" + ",".join("%s=%s" % kv for kv in env.items()), out)
+    return proc.returncode, out
+
+
+@pytest.mark.parametrize("env", _ALT_ENVS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_alternate_paths(env):
+    """One child process per mode (a context reads its knobs once), THREE at a time: with this process that is four users of the
+    card, inside what a GPU box allows; the first of these tests starts them all, each test then waits for its own child."""
+    if os.environ.get("BWTS_TEST_CHILD"):
+        pytest.skip("already inside a child run")
+    if not _alt_pool:
+        from concurrent.futures import ThreadPoolExecutor
+        ex = ThreadPoolExecutor(max_workers=3)
+        for e in _ALT_ENVS:
+            _alt_pool[tuple(sorted(e.items()))] = ex.submit(_alt_child, e)
+    rc, out = _alt_pool[tuple(sorted(env.items()))].result()
+    assert rc == 0, _child_report("alternate_" + ",".join("%s=%s" % kv for kv in env.items()), out)
