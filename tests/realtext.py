@@ -21,3 +21,38 @@ def corpus(limit):
                 if total >= limit:
                     return b"".join(out)[:limit]
     return b"".join(out)
+
+
+# what the >= 1 GiB corpus is made of: the four roots of corpus(), the ROCm headers, and forty Python packages by name -- those that the
+# build container and the GPU boxes hold byte for byte alike (the container has more: its offline wheelhouse), largest first
+BIG_ROOTS = ("/usr/lib/python3/dist-packages", "/usr/lib/python3.10", "/usr/share/doc", "/usr/include", "/opt/rocm/include") + tuple(
+    "/usr/local/lib/python3.10/dist-packages/" + pkg for pkg in (
+        "torch", "sympy", "plotly", "scipy", "pandas", "triton", "fontTools", "numpy", "sqlalchemy", "matplotlib", "networkx", "kaleido",
+        "pygments", "libcst", "textual", "dash_svg", "pymongo", "dash", "mpmath", "narwhals", "pydantic", "hypothesis", "_pytest", "rich",
+        "PIL", "torchgen", "dns", "pybind11", "aiohttp", "google", "joblib", "fastapi", "werkzeug", "fsspec", "scikit_build_core",
+        "mpl_toolkits", "anyio", "multiprocess", "jinja2", "typer"))
+
+
+def corpus_big(limit):
+    """The same kind of material, from more of the image (ROCm headers, Python packages: torch's sources and headers are most of it), up
+    to `limit` bytes: the >= 1 GiB real-text input (tests/golden/realtext_1GiB.json).  Directories in sorted order, depth first; symbolic
+    links are not followed."""
+    out, total = [], 0
+    for root in BIG_ROOTS:
+        for d, dirs, files in os.walk(root):
+            dirs.sort()
+            for f in sorted(files):
+                if not f.endswith((".py", ".txt", ".h", ".hpp", ".md", ".rst", ".c", ".json", ".html")):
+                    continue
+                p = os.path.join(d, f)
+                if os.path.islink(p):
+                    continue
+                try:
+                    b = open(p, "rb").read()
+                except OSError:
+                    continue
+                out.append(b)
+                total += len(b)
+                if total >= limit:
+                    return b"".join(out)[:limit]
+    return b"".join(out)

@@ -1061,6 +1061,23 @@ def test_real_text_vs_oracle(ctx):
     assert np.array_equal(ctx.inverse(y), x)
 
 
+def test_real_text_1GiB_golden(ctx):
+    """1 GiB of REAL text -- Python packages, ROCm headers and data files, source and documentation of this image (tests/realtext.py
+    corpus_big) -- the size BASELINE's metric is quoted on: the device's bytes against the oracle's golden hash
+    (tests/golden/realtext_1GiB.json, made by make_golden_realtext_big.py: the oracle needs ten minutes for it), then the round trip.
+    Skipped where the image's files differ from the golden's."""
+    import realtext
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "realtext_1GiB.json")))
+    x = np.frombuffer(realtext.corpus_big(1 << 30), dtype=np.uint8)
+    if x.size != gold["n"] or hashlib.sha256(x.tobytes()).hexdigest() != gold["sha256_in"]:
+        pytest.skip("this box's file set is not the golden's")
+    y = ctx.forward(x)
+    t = ctx.timings()
+    assert t.active_after_round0 > x.size // 2
+    assert hashlib.sha256(y.tobytes()).hexdigest() == gold["sha256_bwts"]
+    assert np.array_equal(ctx.inverse(y), x)
+
+
 def test_text_1GiB_golden_and_properties(ctx):
     """The bench's text workload at full size, byte-exact against the oracle's golden, then the properties."""
     _properties_at_scale(ctx, "text", 1 << 30, 1, golden=True)
