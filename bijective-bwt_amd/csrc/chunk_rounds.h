@@ -1157,6 +1157,49 @@ struct BlSplitOut {
     }
 };
 
+// (BWTS_ROUND_TRACE only) which of the big list's groups hold one value of the rank at h / of all three ranks: such a group cannot split
+__global__ void bl_diag_flag_kernel(const u64 *__restrict__ bk0, const u64 *__restrict__ k23, u64 m, int rb, u8 *__restrict__ f1, u8 *__restrict__ f23)
+{
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 || j >= m) return;
+    const u64 a = bk0[j], b = bk0[j - 1];
+    if ((a >> rb) != (b >> rb)) return;
+    if (a != b) f1[a >> rb] = 1;
+    if (k23 && k23[j] != k23[j - 1]) f23[a >> rb] = 1;
+}
+__global__ void bl_diag_count_kernel(const u64 *__restrict__ bk0, u64 m, int rb, const u8 *__restrict__ f1, const u8 *__restrict__ f23, unsigned long long *cnt)
+{
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = j < m;
+    const u64 o = in ? bk0[j] >> rb : 0;
+    const u64 c1 = __ballot(in && !f1[o]), c3 = __ballot(in && !f1[o] && !f23[o]);
+    if (lane_id() == 0) { if (c1) atomicAdd(&cnt[0], (unsigned long long)__popcll(c1)); if (c3) atomicAdd(&cnt[1], (unsigned long long)__popcll(c3)); }
+    if (in && j + 1 == m) cnt[2] = o + 1;
+}
+
+// (BWTS_ROUND_TRACE only) elements of the regrouped big list by log2 of their group's size
+__global__ void bl_diag_sizes_kernel(const u32 *__restrict__ rstart, const u32 *__restrict__ rsize, u64 m, unsigned long long *hist)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || rstart[i] != (u32)i) return;
+    const u32 sz = rsize[i];
+    atomicAdd(&hist[31 - __clz(sz)], (unsigned long long)sz);
+    atomicAdd(&hist[32 + 31 - __clz(sz)], 1ull);
+}
+static void bl_diag_sizes(bwts_ctx *ctx, const u32 *rstart, const u32 *rsize, u64 m, const char *what)
+{
+    unsigned long long *d = nullptr, hh[64];
+    if (hipMalloc((void **)&d, sizeof(hh)) != hipSuccess) return;
+    (void)hipMemsetAsync(d, 0, sizeof(hh), ctx->stream);
+    bl_diag_sizes_kernel<<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream>>>(rstart, rsize, m, d);
+    (void)hipMemcpyAsync(hh, d, sizeof(hh), hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    fprintf(stderr, "[chunks] %s: elements (groups) by log2 group size:", what);
+    for (int b = 0; b < 32; b++) if (hh[b]) fprintf(stderr, " %d:%llu(%llu)", b, hh[b], hh[32 + b]);
+    fprintf(stderr, "\n");
+}
+
 static u32 chunk_nominal_size(u64 a)
 {
     // about 16 K chunks, between one and eight tiles each
@@ -1317,6 +1360,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             BlRunIn nin{bl_head[0]};
             BlRunOut nout{bl_head[0], m_big, bv[0], bv[1]};
             CH_TRY((device_scan<true, u32>(ctx, m_big, nin, nout, OpMax(), 0u, sp.scan_temp)));
+            if (round_trace) bl_diag_sizes(ctx, bv[0], bv[1], m_big, "groups of more than 256 after round 0");
             BlSplitIn sin{bv[0], bv[1]};
             BlSplitOut sout{bv[0], bv[1], bl_idx[0], bl_head[0], m_big, st_idx + tail, st_head + tail, bl_idx[1], bl_head[1], (unsigned long long *)slots};
             CH_TRY((device_scan<false, u64>(ctx, m_big, sin, sout, OpAdd(), (u64)0, sp.scan_temp)));
@@ -1381,6 +1425,22 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 BlOut<CYCLIC> fout{bl_head[blc], bl_idx[blc], rb, sp.rank, n, h, d_fstart, k, bk[0], bv[0],
                                    nk == 3 ? k23 : nullptr, nk == 3 ? bk[1] : nullptr, nk == 3 ? bv[1] : nullptr};
                 CH_TRY((device_scan<false, u32>(ctx, m_big, fin, fout, OpAdd(), 0u, sp.scan_temp)));
+                if (round_trace) {
+                    const u64 gcap = m_big / (CH_GROUP_MAX + 1) + 2;
+                    u8 *df = nullptr; unsigned long long hc[3] = {0, 0, 0};
+                    if (hipMalloc((void **)&df, 2 * gcap + 32) == hipSuccess) {
+                        (void)hipMemsetAsync(df, 0, 2 * gcap + 32, ctx->stream);
+                        unsigned long long *dc = (unsigned long long *)(df + ((2 * gcap + 7) & ~7ull));
+                        const unsigned gb = (unsigned)((m_big + 255) / 256);
+                        bl_diag_flag_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(bk[0], nk == 3 ? k23 : nullptr, m_big, rb, df, df + gcap);
+                        bl_diag_count_kernel<<<dim3(gb), dim3(256), 0, ctx->stream>>>(bk[0], m_big, rb, df, df + gcap, dc);
+                        (void)hipMemcpyAsync(hc, dc, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream);
+                        (void)hipStreamSynchronize(ctx->stream);
+                        (void)hipFree(df);
+                        fprintf(stderr, "[chunks] big list at h %llu: %llu elements in %llu groups; in groups with one rank at h: %llu, with one rank triple (cannot split): %llu\n",
+                                (unsigned long long)h, (unsigned long long)m_big, hc[2], hc[0], hc[1]);
+                    }
+                }
             }
             if (nchunks) {
                 SpanGuard g(ctx, BWTS_K_ROUND, 0, 0);
@@ -1430,6 +1490,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 BlRunIn nin{t_head};
                 BlRunOut nout{t_head, m_big, bv[0], bv[1]};
                 CH_TRY((device_scan<true, u32>(ctx, m_big, nin, nout, OpMax(), 0u, sp.scan_temp)));
+                if (round_trace) bl_diag_sizes(ctx, bv[0], bv[1], m_big, "big list regrouped");
                 BlSplitIn sin{bv[0], bv[1]};
                 BlSplitOut sout{bv[0], bv[1], t_idx, t_head, m_big, st_idx + tail, st_head + tail, bl_idx[blc ^ 1], bl_head[blc ^ 1], res};
                 CH_TRY((device_scan<false, u64>(ctx, m_big, sin, sout, OpAdd(), (u64)0, sp.scan_temp)));

@@ -73,6 +73,23 @@ int exclusive_sum_u32(bwts_ctx *ctx, u32 *data, u64 n, void *temp)
 // ------------------------------------------------------------------------------------
 // pass kernels
 // ------------------------------------------------------------------------------------
+// One wave's 64 consecutive digits into its LDS bins.  Sorted and repetitive input (every pass but the first of a sort over text or
+// over ranks with many equal values) puts runs of equal digits into neighbouring lanes, and same-address LDS atomics are served one
+// lane at a time: a pass over such keys ran at 2.4 TB/s where unsorted keys reach 5.6.  So the lanes of a run elect their first one, and
+// it adds the run's length (valid lanes are a prefix of the wave).
+__device__ __forceinline__ void hist_add_runs(u32 *wave_bins, u32 d, bool valid)
+{
+    const int lane = lane_id();
+    const u32 dprev = (u32)__shfl_up((int)d, 1);
+    const bool head = valid && (lane == 0 || d != dprev);
+    const u64 hm = __ballot(head), vm = __ballot(valid);
+    if (head) {
+        const u64 above = lane == 63 ? 0ull : hm >> (lane + 1);
+        const u32 next = above ? (u32)lane + (u32)__ffsll((unsigned long long)above) : (u32)__popcll(vm);
+        atomicAdd(&wave_bins[d], next - (u32)lane);
+    }
+}
+
 template <int RX_THREADS, int RX_ITEMS>
 __global__ __launch_bounds__(RX_THREADS) void radix_hist_kernel(const u64 *__restrict__ keys, u64 m, int shift,
                                                                  u32 *__restrict__ tile_hist)
@@ -94,7 +111,7 @@ __global__ __launch_bounds__(RX_THREADS) void radix_hist_kernel(const u64 *__res
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const u64 i = base + (u64)j * RX_THREADS + tid;
-        if (i < m) atomicAdd(&bins[w][(u32)(k[j] >> shift) & 255u], 1u);
+        hist_add_runs(bins[w], (u32)(k[j] >> shift) & 255u, i < m);
     }
     __syncthreads();
     if (tid < 256) {
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(512) void radix_hist_packed_kernel(const T *__restr
 #pragma unroll
     for (int j = 0; j < RX_ITEMS; j++) {
         const u64 i = base + (u64)j * RX_THREADS + tid;
-        if (i < m) atomicAdd(&bins[w][(u32)(k[j] >> shift) & 255u], 1u);
+        hist_add_runs(bins[w], (u32)(k[j] >> shift) & 255u, i < m);
     }
     __syncthreads();
     if (tid < 256) {

@@ -1,4 +1,5 @@
-"""Fingerprints of the compiled kernels inside libbwts_hip.so: sha256 over a kernel's machine code and its kernel descriptor.
+"""Fingerprints of the compiled kernels inside libbwts_hip.so: sha256 over a kernel's machine code and its kernel descriptor
+(without the descriptor's code-entry offset, which depends on where the linker put the OTHER kernels).
 
 A PMC traffic record under profiles/ vouches for a KERNEL, not for the source file it lives in: bench.py and tools/pmc_summary.py
 tie a record to this fingerprint, so a diagnostic edit elsewhere in the file (a host-side trace line, another kernel) leaves the
@@ -85,10 +86,15 @@ def kernel_fingerprints(lib_path=DEFAULT_LIB):
             if fn is None or fn[3] == 0 or fn[3] >= len(secs):
                 continue
             h = hashlib.sha256()
-            for v, sz, ndx in ((fn[1], fn[2], fn[3]), (value, size, shndx)):
+            for v, sz, ndx, is_kd in ((fn[1], fn[2], fn[3], False), (value, size, shndx, True)):
                 sec = secs[ndx]
                 start = sec["off"] + (v - sec["addr"])
-                h.update(elf[start:start + sz])
+                part = elf[start:start + sz]
+                if is_kd and len(part) >= 24:
+                    # bytes 16..23 = kernel_code_entry_byte_offset: the distance from the descriptor to the code, which moves when
+                    # ANOTHER kernel of the translation unit grows or one is added -- not a property of this kernel
+                    part = part[:16] + b"\0" * 8 + part[24:]
+                h.update(part)
             out[name[:-3]] = h.hexdigest()
     return out
 
