@@ -44,7 +44,7 @@
 #define CH_SLOTS   4                    // result slots of rounds in flight
 #define CH_SLOT_WORDS 16
 #define SM_CHSLOT  (SM_DGCNT + 16)      // CH_SLOTS x CH_SLOT_WORDS words inside the dense rounds' counter block
-enum { CHS_SPLIT = 0, CHS_ERR = 1, CHS_TOTAL = 2, CHS_EXIT = 3, CHS_STAY = 4, CHS_PARKED = 8 };
+enum { CHS_SPLIT = 0, CHS_ERR = 1, CHS_TOTAL = 2, CHS_EXIT = 3, CHS_STAY = 4, CHS_BIGGROUPS = 5, CHS_PARKED = 8 };
 
 // ---- PARKED CHAINS (round 4) ---------------------------------------------------------------------------------------------------
 // Inside a repeated stretch the copies tie position by position: the tied group A = {x_1 .. x_s} is followed, one position on, by the
@@ -1097,21 +1097,56 @@ struct BlOut {
         if (k23) { const u64 v = (r2 << rb) | r3; k23[j] = v; k23_sort[j] = v; j_sort[j] = (u32)j; }
     }
 };
-// after the sorts: new heads, final bytes, new ranks (every gather of the round is done by now), in sorted order
+// after the sorts, in sorted order.  bl_flags_kernel looks at every element and its predecessor once -- first of its group (the ordinal
+// changes), first of its new subgroup (any of the three ranks changes) -- and fetches the element's position; what follows reads
+// the flag bytes and positions in sequence.  (The regrouping scan used to do the comparisons itself, in both of its sweeps: three
+// gathers through the second sort's permutation per element and sweep.)
+#define BLF_GROUP 1u
+#define BLF_SUB   2u
+__global__ __launch_bounds__(256) void bl_flags_kernel(const u64 *__restrict__ bk, const u32 *__restrict__ src, const u64 *__restrict__ k23,
+                                                       const u32 *__restrict__ bv, u64 m, int rb, u8 *__restrict__ flags, u32 *__restrict__ t_idx)
+{
+    const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = j < m;
+    const u64 key = valid ? bk[j] : 0ull;
+    const u32 s = valid ? (src ? src[j] : (u32)j) : 0u;
+    const u64 q = (valid && k23) ? k23[s] : 0ull;
+    if (valid) t_idx[j] = bv[s];
+    u64 kprev = shfl_up_t(key, 1), qprev = shfl_up_t(q, 1);
+    if (lane_id() == 0 && valid && j > 0) { kprev = bk[j - 1]; qprev = k23 ? k23[src ? src[j - 1] : (u32)(j - 1)] : 0ull; }
+    if (!valid) return;
+    const bool gstart = j == 0 || (kprev >> rb) != (key >> rb);
+    const bool sstart = gstart || kprev != key || qprev != q;
+    flags[j] = (u8)((gstart ? BLF_GROUP : 0u) | (sstart ? BLF_SUB : 0u));
+}
+// regrouping scan (max on both halves, see OpMax2): high word = 1 + index of the element's group start, low word = 1 + index of its
+// subgroup start
+struct BlFlagIn {
+    const u8 *flags;
+    __device__ __forceinline__ u64 operator()(u64 j) const
+    {
+        const u32 f = flags[j];
+        return ((u64)((f & BLF_GROUP) ? (u32)j + 1u : 0u) << 32) | (u64)((f & BLF_SUB) ? (u32)j + 1u : 0u);
+    }
+};
+// new heads, final bytes, new ranks (every gather of the round is done by now); and, for the split that follows, every element's
+// subgroup start and -- written by the subgroup's last element -- the subgroup's size
 struct BlRegroupOut {
-    const u64 *bk; const u32 *bv; const u32 *oldhead; u64 m; int rb;
-    u32 *t_idx; u32 *t_head; u32 *rank; PrevSym prev; u8 *out; unsigned long long *result;
-    const u32 *src; const u64 *k23; bool all_bytes;
-    __device__ __forceinline__ void operator()(u64 j, u64 v) const       // inclusive (max, max) scan value, see DgRegroupIn
+    const u8 *flags; const u32 *oldhead; u64 m;
+    const u32 *t_idx; u32 *t_head; u32 *rank; PrevSym prev; u8 *out; unsigned long long *result;
+    u32 *rstart; u32 *rsize; bool all_bytes;
+    __device__ __forceinline__ void operator()(u64 j, u64 v) const       // inclusive (max, max) scan value
     {
         const u32 gidx = (u32)(v >> 32) - 1u, sidx = (u32)v - 1u;
         const u32 newhead = oldhead[j] + (sidx - gidx);        // sorting keeps every group on its own slots, all holding its old head
-        const u32 p = src ? bv[src[j]] : bv[j];
-        t_idx[j] = p; t_head[j] = newhead;
+        const u32 p = t_idx[j];
+        t_head[j] = newhead;
         if (sidx != gidx) rank[p] = newhead;
+        const bool last_of_sub = j + 1 == m || (flags[j + 1] & BLF_SUB);
         // (with parked chains: the byte of every member at its place in its group's slots, alone or not -- ChainCtx::at)
-        const bool last_of_sub = j + 1 == m || bk[j + 1] != bk[j] || (k23 && k23[src[j + 1]] != k23[src[j]]);
         if (out && (all_bytes || (sidx == (u32)j && last_of_sub))) out[newhead + ((u32)j - sidx)] = prev(p);
+        rstart[j] = sidx;
+        if (last_of_sub) rsize[sidx] = (u32)j - sidx + 1u;
         const u64 splitm = __ballot(sidx != gidx);
         if (splitm && lane_id() == __ffsll((unsigned long long)__ballot(true)) - 1 &&
             __hip_atomic_load(&result[CHS_SPLIT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
@@ -1152,7 +1187,12 @@ struct BlSplitOut {
     {
         const u32 c = bl_class(rstart, rsize, i);
         if (c == 1) { const u32 o = (u32)before; x_idx[o] = t_idx[i]; x_head[o] = t_head[i]; }
-        else if (c == 2) { const u32 o = (u32)(before >> 32); s_idx[o] = t_idx[i]; s_head[o] = t_head[i]; }
+        else if (c == 2) {
+            const u32 o = (u32)(before >> 32); s_idx[o] = t_idx[i]; s_head[o] = t_head[i];
+            // (the next round's group ordinals are below this count: it sizes the sort key)
+            const u64 firsts = __ballot(rstart[i] == (u32)i);
+            if (lane_id() == __ffsll((unsigned long long)firsts) - 1) atomicAdd(&result[CHS_BIGGROUPS], (unsigned long long)__popcll(firsts));
+        }
         if (i + 1 == m) { result[CHS_EXIT] = (u64)(u32)before + (c == 1 ? 1u : 0u); result[CHS_STAY] = (before >> 32) + (c == 2 ? 1u : 0u); }
     }
 };
@@ -1325,15 +1365,18 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     const int nk = step4_ok ? 3 : 1;
     u32 *bl_idx[2] = {nullptr, nullptr}, *bl_head[2] = {nullptr, nullptr}, *t_idx = nullptr, *t_head = nullptr, *bv[2] = {nullptr, nullptr}, *sv1 = nullptr;
     u64 *bk[2] = {nullptr, nullptr}, *k23 = nullptr, *sk1 = nullptr;
+    u8 *bflags = nullptr;
+    u64 big_groups = 0;                     // groups in the big list: the ordinals of a round's sort key lie below it
     int blc = 0;
     if (m_big) {
         char *bb = nullptr;
-        CH_TRY(aux_reserve_slot(ctx, 1, 4 * m8 + 9 * m4, &bb));
+        CH_TRY(aux_reserve_slot(ctx, 1, 4 * m8 + 9 * m4 + align_up((size_t)m_big, 256), &bb));
         char *q = bb;
         for (int i = 0; i < 2; i++) { bl_idx[i] = (u32 *)q; q += m4; bl_head[i] = (u32 *)q; q += m4; }
         t_idx = (u32 *)q; q += m4; t_head = (u32 *)q; q += m4;
         bv[0] = (u32 *)q; q += m4; bv[1] = (u32 *)q; q += m4; sv1 = (u32 *)q; q += m4;
         bk[0] = (u64 *)q; q += m8; bk[1] = (u64 *)q; q += m8; k23 = (u64 *)q; q += m8; sk1 = (u64 *)q; q += m8;
+        bflags = (u8 *)q;
         CH_HIP(hipMemcpyAsync(bl_idx[0], st_idx + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
         CH_HIP(hipMemcpyAsync(bl_head[0], st_head + a_small, m_big * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
     }
@@ -1367,7 +1410,8 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         }
         CH_TRY(read_small(ctx, SM_CHSLOT, CH_SLOT_WORDS));
         const u64 m_exit = ctx->h_small[SM_CHSLOT + CHS_EXIT], m_stay = ctx->h_small[SM_CHSLOT + CHS_STAY];
-        if (m_exit + m_stay != m_big || tail + m_exit > a0) CH_FAIL("first split of the big list");
+        big_groups = ctx->h_small[SM_CHSLOT + CHS_BIGGROUPS];
+        if (m_exit + m_stay != m_big || tail + m_exit > a0 || big_groups * (CH_GROUP_MAX + 1) > m_stay) CH_FAIL("first split of the big list");
         if (m_exit) {
             const u32 add = (u32)((m_exit + S - 1) / S);
             if ((u64)nchunks + add > maxchunks) CH_FAIL("chunk table full");
@@ -1452,7 +1496,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                 CH_HIP(hipGetLastError());
             }
             if (m_big) {
-                const int big_bits = bitlen_u64(m_big / (CH_GROUP_MAX + 1)) + rb;          // ordinals < m_big / (CH_GROUP_MAX + 1)
+                const int big_bits = (big_groups > 1 ? bitlen_u64(big_groups - 1) : 1) + rb;          // ordinals < big_groups
                 if (big_bits > 64) return BWTS_E_RANGE;
                 SortPlan bp;
                 bp.tile_hist = sp.tile_hist; bp.scan_temp = sp.scan_temp;
@@ -1483,13 +1527,12 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
                     sorted_k1 = bk[rbig]; positions = bv[rbig];
                 }
                 SpanGuard g(ctx, BWTS_K_RERANK, m_big, 60 * m_big);
-                DgRegroupIn rin{sorted_k1, m_big, rb, src, nk == 3 ? k23 : nullptr};
-                BlRegroupOut rout{sorted_k1, positions, bl_head[blc], m_big, rb, t_idx, t_head, sp.rank, prev, out, res, src, nk == 3 ? k23 : nullptr, parking};
+                bl_flags_kernel<<<dim3((unsigned)((m_big + 255) / 256)), dim3(256), 0, ctx->stream>>>(sorted_k1, src, nk == 3 ? k23 : nullptr, positions, m_big, rb, bflags, t_idx);
+                CH_HIP(hipGetLastError());
+                // (the sort buffers are free again: subgroup starts and sizes go there)
+                BlFlagIn rin{bflags};
+                BlRegroupOut rout{bflags, bl_head[blc], m_big, t_idx, t_head, sp.rank, prev, out, res, bv[0], bv[1], parking};
                 CH_TRY((device_scan<true, u64>(ctx, m_big, rin, rout, OpMax2(), (u64)0, sp.scan_temp)));
-                // (the sort buffers are free again: run starts and lengths go there)
-                BlRunIn nin{t_head};
-                BlRunOut nout{t_head, m_big, bv[0], bv[1]};
-                CH_TRY((device_scan<true, u32>(ctx, m_big, nin, nout, OpMax(), 0u, sp.scan_temp)));
                 if (round_trace) bl_diag_sizes(ctx, bv[0], bv[1], m_big, "big list regrouped");
                 BlSplitIn sin{bv[0], bv[1]};
                 BlSplitOut sout{bv[0], bv[1], t_idx, t_head, m_big, st_idx + tail, st_head + tail, bl_idx[blc ^ 1], bl_head[blc ^ 1], res};
@@ -1515,7 +1558,8 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
             u64 m_exit = 0, m_stay = 0;
             if (m_big) {
                 m_exit = r[CHS_EXIT]; m_stay = r[CHS_STAY];
-                if (m_exit + m_stay > m_big || tail + m_exit > a0) CH_FAIL("big list split counts");
+                big_groups = r[CHS_BIGGROUPS];
+                if (m_exit + m_stay > m_big || tail + m_exit > a0 || big_groups * (CH_GROUP_MAX + 1) > m_stay) CH_FAIL("big list split counts");
             }
             if (in_chunks > a_chunks) CH_FAIL("chunks grew");
 #ifdef CH_PROFILE
