@@ -702,45 +702,90 @@ __global__ __launch_bounds__(256) void lr2_distribute_kernel(const uint4 *__rest
 // ------------------------------------------------------------------------------------
 // MARK_MOMENTS: the unreached elements from the ranges' counts, sums and sums of squares
 // ------------------------------------------------------------------------------------
-// One thread per range.  missing = size - count; one missing index: its offset is (sum of all offsets) - (sum seen); two: their sum A and
-// the sum of their squares B give (o1 - o2)^2 = 2 B - A^2.  More: the range goes onto the list for moments_chase_kernel.
-// counters: [1] unreached elements (as for the other marks), [10] listed ranges, [11] the arithmetic did not come out (fall back to the log)
-__global__ __launch_bounds__(1024) void moments_solve_kernel(const unsigned long long *__restrict__ mom, u64 n, int shift /* log2 of the class count */, const u32 *__restrict__ LF,
-                                                                    u32 *__restrict__ uidx, u32 *__restrict__ ulf, u64 ucap, u32 *__restrict__ def_list,
-                                                                    unsigned long long *__restrict__ counters)
+// missing = size - count; one missing index: its offset is (sum of all offsets) - (sum seen); two: their sum A and the sum of their
+// squares B give (o1 - o2)^2 = 2 B - A^2.  More: the class stays OPEN.
+// Real text leaves a few hundred unreached elements (the cycles of its short Lyndon factors), and with 2^10 classes a few dozen
+// classes miss three or more: what the arithmetic cannot name, the CYCLES can -- an unreached element's whole cycle is unreached, so
+// every element found by arithmetic walks its cycle and the smallest such element of a cycle adds the cycle's members that sit in
+// open classes to the list and to their classes' moments; then the open classes are looked at again (fewer missing now), up to
+// MOM_PASSES times.  Classes still open after that go onto the list for moments_chase_kernel.  One workgroup: the classes are few.
+// cstat[class]: MOM_OPEN, 0 = nothing missing, p = named by arithmetic in pass p.
+// counters: [1] unreached elements (as for the other marks), [10] listed classes, [11] the arithmetic did not come out / no room (fall back to the log)
+#define MOM_OPEN 0xffffffffu
+#define MOM_PASSES 3
+__global__ __launch_bounds__(1024) void moments_resolve_kernel(unsigned long long *__restrict__ mom, u32 *__restrict__ cstat, u64 n, int shift /* log2 of the class count */,
+                                                               const u32 *__restrict__ LF, u32 *__restrict__ uidx, u32 *__restrict__ ulf, u64 ucap,
+                                                               u32 *__restrict__ def_list, unsigned long long *__restrict__ counters, u32 cap)
 {
-    const u64 b = (u64)blockIdx.x * 1024 + threadIdx.x;
+    __shared__ unsigned long long s_from, s_to, s_listed;
     const u64 classes = 1ull << shift;
-    if (b >= classes || b >= n) return;
-    const u64 size = (n - b + classes - 1) >> shift;                         // indices x < n with x mod classes = b: x = o * classes + b, o < size
-    const u64 cnt = mom[b];
-    if (cnt > size) { atomicAdd(&counters[11], 1ull); return; }
-    const u64 d = size - cnt;
-    if (d == 0) return;
-    // sums over all offsets 0 .. size - 1 (mod 2^64: the differences below are small and come out exact)
-    const u64 sall = size * (size - 1) / 2;
-    const u64 a3 = size - 1, b3 = size, c3 = 2 * size - 1;                 // (size-1) size (2 size - 1) / 6, dividing before the products overflow
-    u64 f[3] = {a3, b3, c3};
-    { int two = 0, three = 0; for (int i = 0; i < 3; i++) { if (!two && f[i] % 2 == 0) { f[i] /= 2; two = 1; } } for (int i = 0; i < 3; i++) { if (!three && f[i] % 3 == 0) { f[i] /= 3; three = 1; } } }
-    const u64 qall = f[0] * f[1] * f[2];
-    const u64 A = sall - mom[classes + b], B = qall - mom[2 * classes + b];
-    if (d == 1) {
-        if (A >= size || A * A != B) { atomicAdd(&counters[11], 1ull); return; }
-        const unsigned long long at = atomicAdd(&counters[1], 1ull);
-        if (at < ucap) { const u32 x = (u32)((A << shift) | b); uidx[at] = x; ulf[at] = LF[x]; }
-    } else if (d == 2) {
-        const u64 D = 2 * B - A * A;                                         // (o1 - o2)^2
-        u64 r = (u64)sqrt((double)D);
-        while (r * r > D) r--;
-        while ((r + 1) * (r + 1) <= D) r++;
-        const u64 o1 = (A - r) / 2, o2 = (A + r) / 2;
-        if (r * r != D || r == 0 || ((A - r) & 1) || o2 >= size || o1 * o1 + o2 * o2 != B) { atomicAdd(&counters[11], 1ull); return; }
-        const unsigned long long at = atomicAdd(&counters[1], 2ull);
-        if (at < ucap) { const u32 x = (u32)((o1 << shift) | b); uidx[at] = x; ulf[at] = LF[x]; }
-        if (at + 1 < ucap) { const u32 x = (u32)((o2 << shift) | b); uidx[at + 1] = x; ulf[at + 1] = LF[x]; }
-    } else {
-        const unsigned long long at = atomicAdd(&counters[10], 1ull);
-        def_list[at] = (u32)b;
+    const u32 cmask = (u32)classes - 1u;
+    for (u64 b = threadIdx.x; b < classes; b += 1024) cstat[b] = MOM_OPEN;
+    __threadfence(); __syncthreads();
+    for (u32 pass = 1; pass <= MOM_PASSES + 1; pass++) {
+        const bool arith = pass <= MOM_PASSES;              // the last look only sorts the classes into complete and listed
+        if (threadIdx.x == 0) { s_from = counters[1]; counters[10] = 0; }
+        __threadfence(); __syncthreads();
+        for (u64 b = threadIdx.x; b < classes && b < n; b += 1024) {
+            if (cstat[b] != MOM_OPEN) continue;
+            const u64 size = (n - b + classes - 1) >> shift;                 // indices x < n with x mod classes = b: x = o * classes + b, o < size
+            const u64 cnt = mom[b];
+            if (cnt > size) { atomicAdd(&counters[11], 1ull); continue; }
+            const u64 d = size - cnt;
+            if (d == 0) { cstat[b] = 0; continue; }
+            if (d > 2 || !arith) { const unsigned long long at = atomicAdd(&counters[10], 1ull); def_list[at] = (u32)b; continue; }
+            // sums over all offsets 0 .. size - 1 (mod 2^64: the differences below are small and come out exact)
+            const u64 sall = size * (size - 1) / 2;
+            u64 f[3] = {size - 1, size, 2 * size - 1};                        // (size-1) size (2 size - 1) / 6, dividing before the products overflow
+            { int two = 0, three = 0; for (int i = 0; i < 3; i++) { if (!two && f[i] % 2 == 0) { f[i] /= 2; two = 1; } } for (int i = 0; i < 3; i++) { if (!three && f[i] % 3 == 0) { f[i] /= 3; three = 1; } } }
+            const u64 qall = f[0] * f[1] * f[2];
+            const u64 A = sall - mom[classes + b], B = qall - mom[2 * classes + b];
+            if (d == 1) {
+                if (A >= size || A * A != B) { atomicAdd(&counters[11], 1ull); continue; }
+                const unsigned long long at = atomicAdd(&counters[1], 1ull);
+                if (at < ucap) { const u32 x = (u32)((A << shift) | b); uidx[at] = x; ulf[at] = LF[x]; } else atomicAdd(&counters[11], 1ull);
+            } else {
+                const u64 D = 2 * B - A * A;                                     // (o1 - o2)^2
+                u64 r = (u64)sqrt((double)D);
+                while (r * r > D) r--;
+                while ((r + 1) * (r + 1) <= D) r++;
+                const u64 o1 = (A - r) / 2, o2 = (A + r) / 2;
+                if (r * r != D || r == 0 || ((A - r) & 1) || o2 >= size || o1 * o1 + o2 * o2 != B) { atomicAdd(&counters[11], 1ull); continue; }
+                const unsigned long long at = atomicAdd(&counters[1], 2ull);
+                if (at + 1 < ucap) {
+                    const u32 x1 = (u32)((o1 << shift) | b), x2 = (u32)((o2 << shift) | b);
+                    uidx[at] = x1; ulf[at] = LF[x1]; uidx[at + 1] = x2; ulf[at + 1] = LF[x2];
+                } else atomicAdd(&counters[11], 1ull);
+            }
+            cstat[b] = pass;
+        }
+        __threadfence(); __syncthreads();
+        if (threadIdx.x == 0) { s_to = counters[1]; s_listed = counters[10]; }
+        __syncthreads();
+        if (!arith || s_listed == 0 || counters[11]) break;              // (the same values for every thread: one decision)
+        // the cycles of what this pass named
+        const u64 from = s_from, to = s_to < ucap ? s_to : ucap;
+        for (u64 i = from + threadIdx.x; i < to; i += 1024) {
+            const u32 x = uidx[i];
+            bool leader = true, open_seen = false;
+            u32 steps = 0;
+            for (u32 y = ulf[i]; y != x; y = LF[y]) {
+                const u32 st = cstat[y & cmask];
+                if (st == pass && y < x) { leader = false; break; }
+                if (st == MOM_OPEN) open_seen = true;
+                if (++steps > cap) { atomicAdd(&counters[11], 1ull); leader = false; break; }
+            }
+            if (!leader || !open_seen) continue;
+            for (u32 y = ulf[i]; y != x; y = LF[y]) {
+                const u32 cls = y & cmask;
+                if (cstat[cls] != MOM_OPEN) continue;
+                const unsigned long long at = atomicAdd(&counters[1], 1ull);
+                if (at < ucap) { uidx[at] = y; ulf[at] = LF[y]; } else atomicAdd(&counters[11], 1ull);
+                const unsigned long long o = y >> shift;
+                atomicAdd(&mom[cls], 1ull); atomicAdd(&mom[classes + cls], o); atomicAdd(&mom[2 * classes + cls], o * o);
+            }
+        }
+        __threadfence(); __syncthreads();
     }
 }
 // (own launch, after the one above: all ranges are listed) more elements to search than the budget allows: fall back to the log instead
@@ -752,8 +797,9 @@ __global__ void moments_budget_kernel(unsigned long long *__restrict__ counters,
 // (its cycle holds no splitter: unreached).  `cap` steps without either: counters[11] (the caller falls back to the log).
 __global__ __launch_bounds__(256) void moments_chase_kernel(const u32 *__restrict__ def_list, const unsigned long long *__restrict__ counters_in, u64 n, int shift, int g,
                                                             const u32 *__restrict__ LF, u32 cap, u32 *__restrict__ uidx, u32 *__restrict__ ulf, u64 ucap,
-                                                            unsigned long long *__restrict__ counters)
+                                                            unsigned long long *__restrict__ counters, const u32 *__restrict__ cstat)
 {
+    const u32 cmask = (1u << shift) - 1u;
     const u64 classes = counters_in[10];
     const u64 members = (n + (1ull << shift) - 1) >> shift;                  // quotients a class may hold
     const u64 per = (members + 255) / 256;                                   // 256-element pieces per class
@@ -763,10 +809,13 @@ __global__ __launch_bounds__(256) void moments_chase_kernel(const u32 *__restric
         bool un = false;
         if (x0 < n) {
             if ((x0 & gmask) != 0) {                                         // a splitter is where a walk starts: reached
+                // (a cycle that holds an element of a class no longer open is on the list already: moments_resolve_kernel walked it)
                 u32 y = LF[x0], steps = 0;
+                bool listed = false;
                 for (;;) {
-                    if (y == (u32)x0) { un = true; break; }
+                    if (y == (u32)x0) { un = !listed; break; }
                     if ((y & gmask) == 0) break;
+                    if (cstat[y & cmask] != MOM_OPEN) listed = true;
                     if (++steps > cap) { atomicAdd(&counters[11], 1ull); break; }
                     y = LF[y];
                 }
@@ -945,11 +994,12 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
     BWTS_TRY(arena_reserve(ctx, align_up(n * 4, 256) + radix_tile_hist_bytes(n) + scan_temp_bytes(n) + inverse_node_bytes(node_cap, slot) +
                                     align_up(n, 256) +
                                     (mark == MARK_LOG ? align_up(log_chunks * IDX_CHUNK * 4, 256) + align_up(log_chunks * 4, 256) + align_up(n * 4 + (4ull << IDX_RANGE_LOG2), 256) + (1 << 20) : 0) +
-                                    (1 << 17)));
+                                    (1 << 18)));
     u32 *LF = arena_array<u32>(ctx, n);
     unsigned long long *mom = moments ? (unsigned long long *)arena_array<u64>(ctx, 3 * MOM_MAX_BUCKETS) : nullptr;
-    u32 *def_list = moments ? arena_array<u32>(ctx, MOM_MAX_BUCKETS) : nullptr;
-    if (moments && (!mom || !def_list)) return BWTS_E_NOMEM;
+    unsigned long long *mom_work = moments ? (unsigned long long *)arena_array<u64>(ctx, 3 * MOM_MAX_BUCKETS) : nullptr;   // (moments_resolve_kernel adds to its copy)
+    u32 *def_list = moments ? arena_array<u32>(ctx, MOM_MAX_BUCKETS) : nullptr, *cstat = moments ? arena_array<u32>(ctx, MOM_MAX_BUCKETS) : nullptr;
+    if (moments && (!mom || !mom_work || !def_list || !cstat)) return BWTS_E_NOMEM;
     u32 *tile_hist = (u32 *)arena_alloc(ctx, radix_tile_hist_bytes(n));
     void *scan_temp = arena_alloc(ctx, scan_temp_bytes(n));
     uint4 *noderec = arena_array<uint4>(ctx, node_cap);
@@ -1057,9 +1107,10 @@ static int inverse_attempt(bwts_ctx *ctx, const u8 *d_in, u64 n, u8 *d_out, int 
             if (!first_time) HIPC(hipMemsetAsync(ticket + 10, 0, 2 * sizeof(u64), ctx->stream));
             const u64 per_class = (n + mom_classes - 1) >> mom_shift;
             const u64 budget = (4ull << 20) > per_class ? (4ull << 20) : per_class;        // elements the search may look at (at least one class)
-            moments_solve_kernel<<<dim3((unsigned)((mom_classes + 1023) / 1024)), dim3(1024), 0, ctx->stream>>>(mom, n, mom_shift, LF, uidx, ulf, ucap, def_list, ticket);
+            HIPC(hipMemcpyAsync(mom_work, mom, 3 * mom_classes * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+            moments_resolve_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(mom_work, cstat, n, mom_shift, LF, uidx, ulf, ucap, def_list, ticket, 1u << 16);
             moments_budget_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(ticket, per_class, budget);
-            moments_chase_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(def_list, ticket, n, mom_shift, g, LF, 1u << 16, uidx, ulf, ucap, ticket);
+            moments_chase_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(def_list, ticket, n, mom_shift, g, LF, 1u << 16, uidx, ulf, ucap, ticket, cstat);
         } else if (mark == MARK_LOG) {
             const int bm_bytes = (int)((1u << IDX_RANGE_LOG2) / 8);
             if (first_time) {

@@ -300,6 +300,37 @@ def test_inverse_many_tiny_cycles(ctx):
     assert np.array_equal(ctx.forward(ctx.inverse(z)), z)
 
 
+def _short_factors_text(words, length, tail, seed):
+    """`words` distinct Lyndon words of `length` bytes in decreasing order (each starts with its only smallest byte), then one long
+    Lyndon factor (a single 0, then bytes 1..255): the transform has `words` LF cycles of `length` elements whose ranks lie scattered
+    among the long factor's rotations -- the short leading factors of real text, in numbers."""
+    rng = np.random.default_rng(seed)
+    ws = set()
+    while len(ws) < words:
+        c = int(rng.integers(60, 200))
+        ws.add(bytes([c]) + rng.integers(c + 1, 256, length - 1, dtype=np.uint8).tobytes())
+    body = b"".join(sorted(ws, reverse=True))
+    return np.frombuffer(body + b"\0" + rng.integers(1, 256, tail, dtype=np.uint8).tobytes(), dtype=np.uint8)
+
+
+def test_inverse_unreached_named_by_their_cycles(ctx):
+    """Several hundred unreached elements in short cycles (at this length every 16th element is a splitter: a cycle of 20 meets none
+    with probability 0.27): dozens of residue classes miss three or more elements, which the classes' moments cannot name -- the
+    cycles of the elements they do name can (moments_resolve_kernel).  One walk, not two (bwts_timings.attempts): the 1 GiB of real
+    text used to take two.  With many more such elements few classes name one: the chase or the index log takes over, exact all the same."""
+    x = _short_factors_text(150, 20, 1 << 20, 7)
+    y = O.forward(x)
+    got = ctx.inverse(y)
+    t = ctx.timings()
+    assert np.array_equal(got, x)
+    assert t.unvisited >= 300 and t.factors == 151 and t.attempts == 1
+    x = _short_factors_text(40, 9, (1 << 21) + 77, 8)              # a few hundred: the arithmetic alone, or one round of cycles
+    assert np.array_equal(ctx.inverse(O.forward(x)), x) and ctx.timings().attempts == 1
+    x = _short_factors_text(600, 24, 1 << 20, 9)                   # several per class
+    got = ctx.inverse(O.forward(x))
+    assert np.array_equal(got, x) and ctx.timings().factors == 601
+
+
 def test_inverse_low_entropy_large(pkg):
     """Constant and sorted inputs of 96 / 48 MiB: LF is (close to) the identity, nearly every element sits in a cycle
     without a splitter.  The reference handles any bytes in 4 n memory (unbwts.c:45-52); the engine must stay within a
