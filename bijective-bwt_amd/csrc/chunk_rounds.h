@@ -1370,7 +1370,16 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
     int blc = 0;
     if (m_big) {
         char *bb = nullptr;
-        CH_TRY(aux_reserve_slot(ctx, 1, 4 * m8 + 9 * m4 + align_up((size_t)m_big, 256), &bb));
+        // (nothing outside this function's own buffers has been written so far: without room for the big list the tile form takes over,
+        // as it does when the first two blocks do not fit)
+        const bool deny = [ctx] { const char *e = bwts_knob(ctx, "BWTS_BIGLIST_NOMEM"); return e && atoi(e) == 1; }();      // (test switch)
+        rc = deny ? BWTS_E_NOMEM : aux_reserve_slot(ctx, 1, 4 * m8 + 9 * m4 + align_up((size_t)m_big, 256), &bb);
+        if (rc == BWTS_E_NOMEM) {
+            if (round_trace) fprintf(stderr, "[chunks] no room for the big list (%llu elements): the tile form takes over\n", (unsigned long long)m_big);
+            *handled = false;
+            return BWTS_OK;
+        }
+        CH_TRY(rc);
         char *q = bb;
         for (int i = 0; i < 2; i++) { bl_idx[i] = (u32 *)q; q += m4; bl_head[i] = (u32 *)q; q += m4; }
         t_idx = (u32 *)q; q += m4; t_head = (u32 *)q; q += m4;

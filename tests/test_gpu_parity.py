@@ -300,6 +300,30 @@ def test_inverse_many_tiny_cycles(ctx):
     assert np.array_equal(ctx.forward(ctx.inverse(z)), z)
 
 
+def test_no_room_for_the_big_list_falls_back_to_the_tile_form(pkg, capfd):
+    """Groups of thousands of members go to the chunk rounds' big list, whose buffers are reserved once the list's size is known -- after
+    the first two blocks.  Without room for them the tile form takes over, as it does when the first blocks do not fit (nothing but
+    the function's own buffers has been written by then): same bytes, no error.  BWTS_BIGLIST_NOMEM=1 refuses that reservation."""
+    rng = np.random.default_rng(5)
+    phrase = rng.integers(97, 123, 200, dtype=np.uint8)
+    x = np.concatenate([np.tile(phrase, 5000), O.generate("zipf", 1 << 20, 4)])
+    want = O.forward(x)
+    saved = {k: os.environ.get(k) for k in ("BWTS_TEST_KNOBS", "BWTS_BIGLIST_NOMEM", "BWTS_ROUND_TRACE")}
+    try:
+        os.environ.update(BWTS_TEST_KNOBS="1", BWTS_BIGLIST_NOMEM="1", BWTS_ROUND_TRACE="1")
+        with pkg.Context(0) as ctx:                      # (a context reads its switches when it is made)
+            got = ctx.forward(x)
+            assert "no room for the big list" in capfd.readouterr().err          # (the input does have one, and it was refused)
+            assert np.array_equal(got, want)
+            assert np.array_equal(ctx.inverse(got), x)
+    finally:
+        for k, v in saved.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    with pkg.Context(0) as ctx:
+        assert np.array_equal(ctx.forward(x), want)
+
+
 def _short_factors_text(words, length, tail, seed):
     """`words` distinct Lyndon words of `length` bytes in decreasing order (each starts with its only smallest byte), then one long
     Lyndon factor (a single 0, then bytes 1..255): the transform has `words` LF cycles of `length` elements whose ranks lie scattered
