@@ -285,7 +285,56 @@ def _roofline(kernel, st, traffic, traffic_src, note, per_forward=None):
     return r
 
 
-def _e2e(ctx, helper, d_in, d_out, n, workload):
+def _cli_runs(helper, src, out, rt, n, pause_s=0.0):
+    """mk_bwts src -> out, [pause,] unbwts out -> rt through the helper process: walls, rates, the programs' own phase lines."""
+    env = dict(os.environ, BWTS_TIMINGS="1")
+
+    def ask(cmd):
+        helper.stdin.write(json.dumps({"cmd": cmd, "env": env}) + "\n")
+        helper.stdin.flush()
+        return json.loads(helper.stdout.readline())
+
+    pkg_dir = os.path.join(ROOT, "bijective-bwt_amd")
+    a = ask([os.path.join(pkg_dir, "mk_bwts"), src, out])
+    if pause_s: time.sleep(pause_s)
+    b = ask([os.path.join(pkg_dir, "unbwts"), out, rt])
+
+    def phases(r):
+        lines = [l for l in r["stderr"].splitlines() if " time" in l][-8:]
+        for l in lines:
+            if l.startswith("Process time") and "since launch" in l:        # what follows main(): exit handlers, the driver taking the memory back
+                lines.append("After main() %.3f" % (r["wall_s"] - float(l.rsplit("since launch", 1)[1].split()[0])))
+                break
+        return lines
+    return {"ok": a["rc"] == 0 and b["rc"] == 0,
+            "wall_s": {"mk_bwts": round(a["wall_s"], 3), "unbwts": round(b["wall_s"], 3)},
+            "MBps": (round(n / 1e6 / a["wall_s"], 1) if a["rc"] == 0 else None, round(n / 1e6 / b["wall_s"], 1) if b["rc"] == 0 else None),
+            "phases": {"mk_bwts": phases(a), "unbwts": phases(b)}, "stderr": (a["stderr"] + b["stderr"])[-500:]}
+
+
+def _cli_first(ctx, helper, d_in, n, workload, seed):
+    """The two programs on a tmpfs file BEFORE this process has freed any device memory, each on a device at rest (a pause before
+    unbwts): what a user who runs `mk_bwts file` meets.  Then the pair once more back to back: device memory that has been freed -- by
+    a process that has just exited, or by a living one -- is scrubbed by the driver before it is used again, 30-40 ms per GiB, and
+    whoever allocates next waits for it: unbwts started right behind mk_bwts waits for mk_bwts' 27 GiB.
+    The files stay until _e2e has compared them with the device path."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    td = tempfile.mkdtemp(prefix="bwts_bench_", dir=base)
+    import atexit
+    atexit.register(shutil.rmtree, td, True)         # (tmpfs is memory: the files go whatever becomes of the run)
+    src, out, rt = os.path.join(td, "in.bin"), os.path.join(td, "out.bwts"), os.path.join(td, "back.bin")
+    ctx.generate(workload, seed, n, d_in)
+    d_in.download().tofile(src)
+    r = _cli_runs(helper, src, out, rt, n, pause_s=2.0)
+    time.sleep(2.0)
+    out2, rt2 = out + ".2", rt + ".2"
+    r2 = _cli_runs(helper, src, out2, rt2, n)
+    for f in (out2, rt2):
+        if os.path.exists(f): os.remove(f)
+    return {"runs": r, "back_to_back": r2, "dir": td, "src": src, "out": out, "rt": rt, "base": base or td}
+
+
+def _e2e(ctx, helper, d_in, d_out, n, workload, cli_pre=None):
     """The path the CLIs take: caller-owned, unpinned host buffers (bwts_forward / bwts_inverse), and the mk_bwts / unbwts
     programs on files in tmpfs, started by the helper process."""
     import numpy as np
@@ -346,42 +395,24 @@ def _e2e(ctx, helper, d_in, d_out, n, workload):
                         "inputs": "%s seeds 1..%d, unpinned numpy arrays; outputs allocated (untouched) inside the call" % (workload, items)}
         del xs, ys, backs
 
-    if helper is not None:
-        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-        td = tempfile.mkdtemp(prefix="bwts_bench_", dir=base)
+    if helper is not None and cli_pre is not None:
         try:
-            src, out, rt = os.path.join(td, "in.bin"), os.path.join(td, "out.bwts"), os.path.join(td, "back.bin")
-            x.tofile(src)
-            env = dict(os.environ, BWTS_TIMINGS="1")
-
-            def ask(cmd):
-                helper.stdin.write(json.dumps({"cmd": cmd, "env": env}) + "\n")
-                helper.stdin.flush()
-                return json.loads(helper.stdout.readline())
-
-            pkg_dir = os.path.join(ROOT, "bijective-bwt_amd")
-            a = ask([os.path.join(pkg_dir, "mk_bwts"), src, out])
-            b = ask([os.path.join(pkg_dir, "unbwts"), out, rt])
-            ok = a["rc"] == 0 and b["rc"] == 0
-            res["cli_wall_MBps"] = round(n / 1e6 / a["wall_s"], 1) if a["rc"] == 0 else None
-            res["cli_inverse_wall_MBps"] = round(n / 1e6 / b["wall_s"], 1) if b["rc"] == 0 else None
-            res["cli_wall_s"] = {"mk_bwts": round(a["wall_s"], 3), "unbwts": round(b["wall_s"], 3)}
-            def phases(r):
-                lines = [l for l in r["stderr"].splitlines() if " time" in l][-8:]
-                for l in lines:
-                    if l.startswith("Process time") and "since launch" in l:        # what follows main(): exit handlers, the driver taking the memory back
-                        lines.append("After main() %.3f" % (r["wall_s"] - float(l.rsplit("since launch", 1)[1].split()[0])))
-                        break
-                return lines
-            res["cli_phases"] = {"mk_bwts": phases(a), "unbwts": phases(b)}
-            if ok:
-                res["cli_output_equals_device_path"] = bool(np.array_equal(np.fromfile(out, dtype=np.uint8), ymem))
-                res["cli_roundtrip_exact"] = bool(np.array_equal(np.fromfile(rt, dtype=np.uint8), x))
+            r = cli_pre["runs"]
+            res["cli_wall_MBps"], res["cli_inverse_wall_MBps"] = r["MBps"]
+            res["cli_wall_s"] = r["wall_s"]
+            res["cli_phases"] = r["phases"]
+            if r["ok"]:
+                res["cli_output_equals_device_path"] = bool(np.array_equal(np.fromfile(cli_pre["out"], dtype=np.uint8), ymem))
+                res["cli_roundtrip_exact"] = bool(np.array_equal(np.fromfile(cli_pre["rt"], dtype=np.uint8), x))
             else:
-                res["cli_error"] = (a["stderr"] + b["stderr"])[-500:]
-            res["cli_files"] = "tmpfs (%s); wall time of the whole process: HIP start-up, context, mmap, transform, write" % (base or td)
+                res["cli_error"] = r["stderr"]
+            res["cli_files"] = ("tmpfs (%s); wall time of the whole process: HIP start-up, context, mmap, transform, write; run before this "
+                                "process had freed any device memory, 2 s apart (back to back: cli_wall_back_to_back_s)" % cli_pre["base"])
+            r2 = cli_pre["back_to_back"]
+            res["cli_wall_back_to_back_s"] = r2["wall_s"]
+            res["cli_phases_back_to_back"] = {k: [l for l in v if l.startswith(("Process time", "Start-up time", "After main"))] for k, v in r2["phases"].items()}
         finally:
-            shutil.rmtree(td, ignore_errors=True)
+            shutil.rmtree(cli_pre["dir"], ignore_errors=True)
     return res
 
 
@@ -457,6 +488,12 @@ def main(argv=None):
     d_in = ctx.alloc(n)
     d_out = ctx.alloc(n)
     d_back = ctx.alloc(n)
+    cli_pre = None
+    if helper is not None:
+        try:
+            cli_pre = _cli_first(ctx, helper, d_in, n, args.workload, 1 + rank)
+        except Exception as e:
+            print("bench.py: CLI leg failed: %r" % (e,), file=sys.stderr)
 
     def measure(workload, steps, warmup, inverse_steps, breakdown_steps):
         """K timed forward steps (HIP events only on the dominant kernel), the inverse + round trip, then the breakdown."""
@@ -578,7 +615,7 @@ def main(argv=None):
         if n_gpus == 1 and not selftest:
             if not args.no_e2e:
                 try:
-                    line["e2e"] = _e2e(ctx, helper, d_in, d_out, n, args.workload)
+                    line["e2e"] = _e2e(ctx, helper, d_in, d_out, n, args.workload, cli_pre)
                 except Exception as e:       # the headline stands on its own; a failure here is reported, not hidden
                     line["e2e"] = {"error": repr(e)}
             if not args.no_text and args.workload != "text":
