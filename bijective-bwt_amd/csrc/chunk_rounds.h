@@ -1240,6 +1240,32 @@ static void bl_diag_sizes(bwts_ctx *ctx, const u32 *rstart, const u32 *rsize, u6
     fprintf(stderr, "\n");
 }
 
+// (BWTS_ROUND_TRACE only) elements of the chunks by the size of their group: 2, 3-4, 5-16, 17-64, 65-256, 257-2048
+__global__ __launch_bounds__(256) void chunk_diag_sizes_kernel(const u32 *__restrict__ head, const u32 *__restrict__ cstart, const u32 *__restrict__ ccount, unsigned long long *hist)
+{
+    const u32 c = blockIdx.x, cnt = ccount[c];
+    const u64 base = cstart[c];
+    for (u32 i = threadIdx.x; i < cnt; i += 256) {
+        if (i && head[base + i] == head[base + i - 1]) continue;
+        u32 e = i + 1;
+        while (e < cnt && head[base + e] == head[base + i]) e++;
+        const u32 sz = e - i;
+        const int cls = sz <= 2 ? 0 : sz <= 4 ? 1 : sz <= 16 ? 2 : sz <= 64 ? 3 : sz <= 256 ? 4 : 5;
+        atomicAdd(&hist[cls], (unsigned long long)sz);
+    }
+}
+static void chunk_diag_sizes(bwts_ctx *ctx, const u32 *head, const u32 *cstart, const u32 *ccount, u32 nchunks, u32 round)
+{
+    unsigned long long *d = nullptr, hh[6];
+    if (!nchunks || hipMalloc((void **)&d, sizeof(hh)) != hipSuccess) return;
+    (void)hipMemsetAsync(d, 0, sizeof(hh), ctx->stream);
+    chunk_diag_sizes_kernel<<<dim3(nchunks), dim3(256), 0, ctx->stream>>>(head, cstart, ccount, d);
+    (void)hipMemcpyAsync(hh, d, sizeof(hh), hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    fprintf(stderr, "[chunks] before round %u, chunk elements by group size: 2: %llu  3-4: %llu  5-16: %llu  17-64: %llu  65-256: %llu  257-2048: %llu\n", round, hh[0], hh[1], hh[2], hh[3], hh[4], hh[5]);
+}
+
 static u32 chunk_nominal_size(u64 a)
 {
     // about 16 K chunks, between one and eight tiles each
@@ -1454,6 +1480,7 @@ static int chunk_rounds(bwts_ctx *ctx, const u8 *d_T, u64 n, const Alphabet &al,
         for (int b = 0; b < B; b++) {
             unsigned long long *res = (unsigned long long *)(slots + b * CH_SLOT_WORDS);
             hs[b] = h;
+            if (round_trace && nchunks) chunk_diag_sizes(ctx, st_head, cstart, ccount, nchunks, rounds + 1);
             if (nchunks) {
                 SpanGuard g(ctx, BWTS_K_ROUND, 0, 0);          // (elements and bytes are added below, once the round's true size is known)
 #define CH_LAUNCH_P(NK, FS, WD, PK) chunk_round_kernel<CYCLIC, NK, FS, WD, PK><<<dim3(nchunks), dim3(CH_THREADS), 0, ctx->stream>>>(st_idx, st_head, cstart, ccount, cwide, mv, mvcount, \
