@@ -76,14 +76,18 @@ int exclusive_sum_u32(bwts_ctx *ctx, u32 *data, u64 n, void *temp)
 // One wave's 64 consecutive digits into its LDS bins.  Sorted and repetitive input (every pass but the first of a sort over text or
 // over ranks with many equal values) puts runs of equal digits into neighbouring lanes, and same-address LDS atomics are served one
 // lane at a time: a pass over such keys ran at 2.4 TB/s where unsorted keys reach 5.6.  So the lanes of a run elect their first one, and
-// it adds the run's length (valid lanes are a prefix of the wave).
+// it adds the run's length (valid lanes are a prefix of the wave).  The neighbour's digit comes through DPP (row_shr:1 -- no trip
+// through the LDS crossbar, which cost the 2-byte sweep over random digits 0.15 ms of 0.45); a row's first lane has no neighbour
+// there and starts a run of its own: runs are at most 16 long.
 __device__ __forceinline__ void hist_add_runs(u32 *wave_bins, u32 d, bool valid)
 {
     const int lane = lane_id();
-    const u32 dprev = (u32)__shfl_up((int)d, 1);
-    const bool head = valid && (lane == 0 || d != dprev);
+    const u32 dprev = (u32)__builtin_amdgcn_update_dpp((int)d, (int)d, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    const bool head = valid && ((lane & 15) == 0 || d != dprev);
     const u64 hm = __ballot(head), vm = __ballot(valid);
-    if (head) {
+    if (hm == vm) {                              // (no two neighbours alike -- three waves in four on random digits: nothing to add up)
+        if (valid) atomicAdd(&wave_bins[d], 1u);
+    } else if (head) {
         const u64 above = lane == 63 ? 0ull : hm >> (lane + 1);
         const u32 next = above ? (u32)lane + (u32)__ffsll((unsigned long long)above) : (u32)__popcll(vm);
         atomicAdd(&wave_bins[d], next - (u32)lane);
