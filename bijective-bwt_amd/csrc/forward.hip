@@ -969,6 +969,10 @@ struct GroupOut {
 // from __ballot); the scan then runs over n/64 words instead of n elements, and tied_from_flags_kernel turns the set
 // bits into the tied list.  Same outputs as GroupIn/GroupOut with rb < 0, a third of the time.
 #define GF_WORDS 8      // words (of 64 slots) a wave handles per step: eight key loads in flight per lane
+// A slot starts a group when its key differs from the slot before; it is the last of its group when the NEXT slot starts one: so only
+// the left neighbour's key is fetched (DPP wave_shr:1 on the two halves; lane 0 takes the word before's lane 63 from a scalar), and
+// "last of its group" is the start mask shifted by one, as scalar arithmetic on the ballot words.  (The first version brought both
+// neighbours through the LDS crossbar, eight ds_bpermute per element: 2.45 ms at 2^30 where the keys stream in 1.7.)
 __global__ __launch_bounds__(256) void group_flags_kernel(const u64 *__restrict__ K, u64 n, u64 *__restrict__ headw, u64 *__restrict__ keepw,
                                                           u64 mask = ~0ull /* key bits that count (the 64-bit path parks position bits above them) */)
 {
@@ -976,30 +980,40 @@ __global__ __launch_bounds__(256) void group_flags_kernel(const u64 *__restrict_
     const u64 words = (n + 63) / 64;
     const u64 wave = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6, waves = ((u64)gridDim.x * 256) >> 6;
     for (u64 w0 = wave * GF_WORDS; w0 < words; w0 += waves * GF_WORDS) {
+        // (unconditional loads from clamped indices: a load under `i < n ? ... : 0` becomes a branch with a wait for the data behind it,
+        // ONE load in flight per wave -- which is how this kernel ran at 3.5 TB/s for three rounds; what a slot past the end holds is
+        // never looked at)
         u64 k[GF_WORDS];
 #pragma unroll
         for (int q = 0; q < GF_WORDS; q++) {
             const u64 i = (w0 + q) * 64 + lane;
-            k[q] = i < n ? K[i] & mask : 0;
+            k[q] = K[i < n ? i : n - 1] & mask;
         }
-        const u64 first = w0 * 64, last = (w0 + GF_WORDS) * 64 - 1;      // the chunk's outer neighbours
-        u64 edge = 0;
-        if (lane == 0 && first > 0) edge = K[first - 1] & mask;
-        if (lane == 63 && last + 1 < n) edge = K[last + 1] & mask;
-        u64 mine_h = 0, mine_k = 0;
+        const u64 first = w0 * 64, after = (w0 + GF_WORDS) * 64;          // the chunk's outer neighbours: slots first - 1 and after
+        const u64 before_key = K[first > 0 ? first - 1 : 0] & mask;          // (uniform addresses: scalar loads)
+        const u64 after_key = K[after < n ? after : n - 1] & mask;
+        u64 hm[GF_WORDS], vm[GF_WORDS];        // per word: slots that start a group (slots past the end count as starts), valid slots
+        u64 prev63 = before_key;
 #pragma unroll
         for (int q = 0; q < GF_WORDS; q++) {
             const u64 i = (w0 + q) * 64 + lane;
-            u64 kp = shfl_up_t(k[q], 1), kn = shfl_down_t(k[q], 1);
-            const u64 prev63 = q > 0 ? shfl_t(k[q > 0 ? q - 1 : 0], 63) : edge;              // lane 0 reads it
-            const u64 next0 = q + 1 < GF_WORDS ? shfl_t(k[q + 1 < GF_WORDS ? q + 1 : q], 0) : edge;   // lane 63 reads it
-            if (lane == 0) kp = prev63;
-            if (lane == 63) kn = next0;
+            const u32 lo = (u32)k[q], hi = (u32)(k[q] >> 32);
+            const u32 plo = (u32)__builtin_amdgcn_update_dpp((int)lo, (int)lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const u32 phi = (u32)__builtin_amdgcn_update_dpp((int)hi, (int)hi, 0x138, 0xf, 0xf, false);
             const bool valid = i < n;
-            const bool f0 = valid && (i == 0 || k[q] != kp);
-            const bool f1 = valid && (i + 1 == n || kn != k[q]);
-            const u64 hm = __ballot(f0), km = __ballot(valid && !(f0 && f1));
-            if (lane == q) { mine_h = hm; mine_k = km; }
+            const bool diff = lane == 0 ? (i == 0 || k[q] != prev63) : (lo != plo || hi != phi);
+            vm[q] = __ballot(valid);
+            hm[q] = __ballot(!valid || diff);
+            prev63 = ((u64)(u32)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)lo, 63);
+        }
+        const bool after_starts = after >= n || after_key != prev63;          // does slot `after` start a group (or lie past the end)?
+        u64 mine_h = 0, mine_k = 0;
+#pragma unroll
+        for (int q = 0; q < GF_WORDS; q++) {
+            const u64 nextbit = q + 1 < GF_WORDS ? (hm[q + 1 < GF_WORDS ? q + 1 : q] & 1ull) : (after_starts ? 1ull : 0ull);
+            const u64 lastm = (hm[q] >> 1) | (nextbit << 63);                   // slots whose successor starts a group
+            const u64 h = hm[q] & vm[q];
+            if (lane == q) { mine_h = h; mine_k = vm[q] & ~(h & lastm); }
         }
         if (lane < GF_WORDS && w0 + lane < words) { headw[w0 + lane] = mine_h; keepw[w0 + lane] = mine_k; }
     }

@@ -44,18 +44,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(u64 n, InF in
 {
     __shared__ T sm[SCAN_THREADS / 64];
     const u64 base = (u64)blockIdx.x * SCAN_TILE + threadIdx.x;
+    // The input functor is evaluated for EVERY item, at an index clamped into the range, and the value of an item past the end is
+    // dropped: under `if (i < n)` each item's loads sat behind a branch with a wait for the data right after them -- one load in flight
+    // per wave, in every scan of the library.  (Input functors only read.)
     T acc = identity;
     typename scan_raw_of<InF>::type raw[SCAN_ITEMS];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
         const u64 i = base + (u64)j * SCAN_THREADS;
-        if (i < n) raw[j] = scan_load_<InF, T>(in, i, scan_rank<1>());
+        raw[j] = scan_load_<InF, T>(in, i < n ? i : n - 1, scan_rank<1>());
     }
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
         const u64 i = base + (u64)j * SCAN_THREADS;
         u32 note;
-        if (i < n) acc = op(acc, scan_make_<InF, typename scan_raw_of<InF>::type, T>(in, i, raw[j], &note, scan_rank<1>()));
+        const T v = scan_make_<InF, typename scan_raw_of<InF>::type, T>(in, i < n ? i : n - 1, raw[j], &note, scan_rank<1>());
+        acc = i < n ? op(acc, v) : acc;
     }
     T inc = wave_scan_inclusive(acc, op);
     if (lane_id() == 63) sm[wave_id()] = inc;
@@ -105,14 +109,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(u64 n, InF in,
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; j++) {
             const u64 i = tile_base + (u32)j * SCAN_THREADS + threadIdx.x;
-            if (i < n) raw[j] = scan_load_<InF, T>(in, i, scan_rank<1>());
+            raw[j] = scan_load_<InF, T>(in, i < n ? i : n - 1, scan_rank<1>());        // (clamped, unconditional: see scan_reduce_kernel)
         }
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; j++) {
             const u32 e = (u32)j * SCAN_THREADS + threadIdx.x;
             const u64 i = tile_base + e;
             note[j] = 0;
-            tile[SCAN_SLOT(e)] = i < n ? scan_make_<InF, typename scan_raw_of<InF>::type, T>(in, i, raw[j], &note[j], scan_rank<1>()) : identity;
+            const T v = scan_make_<InF, typename scan_raw_of<InF>::type, T>(in, i < n ? i : n - 1, raw[j], &note[j], scan_rank<1>());
+            tile[SCAN_SLOT(e)] = i < n ? v : identity;
         }
     }
     __syncthreads();
