@@ -193,6 +193,8 @@ __global__ __launch_bounds__(CH_THREADS, WIDE ? 4 : CH_MIN_WAVES) void chunk_rou
         CH_MARK(0);
         // successor ranks: they depend on the positions alone, so the gathers are issued now and fly while the group extents are
         // worked out (slots of a group that is left for the next tile are gathered for nothing)
+        // (Round 4 tried all twelve gathers of a lane in one straight run of loads -- the compiler drains them item by item, three in
+        // flight, because the next item's factor search stands between: 8 % SLOWER, five more spilled registers and no shorter waits.)
         u32 my_key[CH_ITEMS];
         u64 my_key23[NKEYS == 3 ? CH_ITEMS : 1];
         u32 ppos[CH_ITEMS];                      // position of the previous symbol, T[cprev(p)] (mk_bwts_sa.c:172-188), while the factor is at hand
@@ -649,13 +651,21 @@ __global__ __launch_bounds__(256) void chunk_apply_records_kernel(u64 *__restric
         const u32 c = blockIdx.x;
         const u32 m = mvcount[c];
         const u64 base = cstart[c];
-        for (u32 i = threadIdx.x; i < m; i += 256) {
-            const u64 e = mv[base + i];
-            const u32 q = (u32)e, nr = (u32)(e >> 32);
-            cx.rank[q] = nr;
-            if (MODE == 1) {
-                if (cx.out) cx.out[nr] = cx.prev((u64)q);
-                if (cx.SA) cx.SA[nr] = q;
+        // (four records per lane and step, read before any of them is applied: the rank array may alias the records as far as the
+        // compiler knows, so one by one every record's load waited for the store before it)
+        for (u32 i0 = 0; i0 < m; i0 += 1024) {
+            u64 e[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const u32 i = i0 + (u32)t * 256 + threadIdx.x; e[t] = mv[base + (i < m ? i : m - 1)]; }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (i0 + (u32)t * 256 + threadIdx.x >= m) continue;
+                const u32 q = (u32)e[t], nr = (u32)(e[t] >> 32);
+                cx.rank[q] = nr;
+                if (MODE == 1) {
+                    if (cx.out) cx.out[nr] = cx.prev((u64)q);
+                    if (cx.SA) cx.SA[nr] = q;
+                }
             }
         }
         return;

@@ -53,11 +53,20 @@ __device__ __forceinline__ void dg_detect(const u32 *__restrict__ idx, const u32
 {
     const int tid = threadIdx.x, lane = tid & 63;
     bool valid[DG_ITEMS];
+    u32 own_idx[DG_ITEMS];
+    // (head and position of every slot up front, from indices clamped into the list: a load under a condition is compiled to a branch
+    // with a wait behind it, one load in flight per wave -- and the position used to be fetched at the very end, item by item)
 #pragma unroll
     for (int j = 0; j < DG_ITEMS; j++) {
         const long long e = e0 + j * DG_THREADS + tid;
         valid[j] = e >= 0 && (u64)e < a;
-        ds.h[j] = valid[j] ? head[e] : 0u;
+        const u64 ec = e < 0 ? 0ull : ((u64)e < a ? (u64)e : a - 1);
+        ds.h[j] = head[ec];
+        own_idx[j] = idx[ec];
+    }
+#pragma unroll
+    for (int j = 0; j < DG_ITEMS; j++) {
+        if (!valid[j]) ds.h[j] = 0u;
         hd[j * DG_THREADS + tid] = ds.h[j];
     }
     __syncthreads();
@@ -100,7 +109,7 @@ __device__ __forceinline__ void dg_detect(const u32 *__restrict__ idx, const u32
         if (small) {
             if (gs >= DG_CAP && gs < DG_CAP + DG_OWN) { ds.kind[j] = 1; ds.gs[j] = (u32)gs; ds.sz[j] = (u32)(ge - gs); }
         } else if (sl >= DG_CAP && sl < DG_CAP + DG_OWN) ds.kind[j] = 2;
-        if (ds.kind[j]) ds.idx[j] = idx[e0 + sl];
+        if (ds.kind[j]) ds.idx[j] = own_idx[j];
     }
 }
 

@@ -1045,16 +1045,32 @@ __global__ __launch_bounds__(256) void tied_from_flags_kernel(const u64 *__restr
         if (w < words) { hm = headw[w]; km = keepw[w]; pr = pre[w]; }
         if (w + 1 == words) *cnt_active = (u64)(u32)pr + (u64)__popcll(km);
         u64 todo = __ballot(km != 0);
+        // four words per step, their positions fetched together (whole words, from indices clamped into the array): a word's stores wait
+        // for its load, so taken one at a time the words went by at one load latency each
         while (todo) {
-            const int q = __ffsll((unsigned long long)todo) - 1;
-            todo &= todo - 1;
-            const u64 h = shfl_t(hm, q), kk = shfl_t(km, q), pq = shfl_t(pr, q);
-            if ((kk >> lane) & 1ull) {
-                const u64 i = (wb + q) * 64 + lane;
-                const u64 below = lane == 63 ? h : h & ((2ull << lane) - 1ull);        // group starts at or before this slot
-                const u32 head = below ? (u32)((wb + q) * 64 + (u64)(63 - __clzll((long long)below))) : (u32)(pq >> 32);
-                const u32 dst = (u32)pq + (u32)__popcll(kk & lanemask_lt());
-                n_idx[dst] = V[i]; n_slot[dst] = (u32)i; n_head[dst] = head;
+            int q[4];
+            u32 v[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                q[t] = todo ? __ffsll((unsigned long long)todo) - 1 : -1;
+                todo &= todo - 1;                                   // (0 stays 0)
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const u64 i = (wb + (u64)(q[t] < 0 ? 0 : q[t])) * 64 + lane;
+                v[t] = V[i < n ? i : n - 1];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (q[t] < 0) continue;
+                const u64 h = shfl_t(hm, q[t]), kk = shfl_t(km, q[t]), pq = shfl_t(pr, q[t]);
+                if ((kk >> lane) & 1ull) {
+                    const u64 i = (wb + q[t]) * 64 + lane;
+                    const u64 below = lane == 63 ? h : h & ((2ull << lane) - 1ull);        // group starts at or before this slot
+                    const u32 head = below ? (u32)((wb + q[t]) * 64 + (u64)(63 - __clzll((long long)below))) : (u32)(pq >> 32);
+                    const u32 dst = (u32)pq + (u32)__popcll(kk & lanemask_lt());
+                    n_idx[dst] = v[t]; n_slot[dst] = (u32)i; n_head[dst] = head;
+                }
             }
         }
     }
