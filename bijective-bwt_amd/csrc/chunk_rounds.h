@@ -1059,12 +1059,16 @@ __global__ __launch_bounds__(256) void go_expand_kernel(const u64 *__restrict__ 
             if (pinfo) { pinfo[(u32)k] = 2; pinfo[(u32)(k >> 32)] = 2; }
         } else { e = (u32)(k >> 32) & (pairs ? 0x7fffffffu : 0xffffffffu); sz = v; }
     }
-    if (sz && sz <= 4) {
+    {
+        // (a short group's members: four loads issued together, from the group's first slot where it has fewer -- not one behind a test each)
+        const bool few = sz && sz <= 4;
         u32 pi[4];
 #pragma unroll
-        for (u32 t = 0; t < 4; t++) pi[t] = t < sz ? SA[(u64)e + t] : 0u;
+        for (u32 t = 0; t < 4; t++) pi[t] = SA[(u64)e + (few && t < sz ? t : 0u)];
+        if (few) {
 #pragma unroll
-        for (u32 t = 0; t < 4; t++) if (t < sz) { st_idx[d + t] = pi[t]; st_head[d + t] = e; if (pinfo) pinfo[pi[t]] = (u8)sz; }
+            for (u32 t = 0; t < 4; t++) if (t < sz) { st_idx[d + t] = pi[t]; st_head[d + t] = e; if (pinfo) pinfo[pi[t]] = (u8)sz; }
+        }
     }
     u64 longm = __ballot(sz > 4);
     while (longm) {
