@@ -26,7 +26,7 @@ PKG = os.path.join(ROOT, "bijective-bwt_amd")
 # kernel-level
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,bits", [(1, 8), (2, 1), (63, 8), (64, 16), (65, 64), (4095, 24), (4096, 32), (4097, 64),
-                                    (100003, 40), (1 << 20, 64), (3 << 20, 63)])
+                                    (100003, 40), (1 << 20, 64), (3 << 20, 63), (10_000_000, 48)])
 def test_radix_sort_pairs_stable(ctx, m, bits):
     rng = np.random.default_rng(m * 131 + bits)
     k = rng.integers(0, 2**63, size=m, dtype=np.uint64)
@@ -39,6 +39,20 @@ def test_radix_sort_pairs_stable(ctx, m, bits):
     order = np.argsort(k, kind="stable")
     assert np.array_equal(ks, k[order])
     assert np.array_equal(vs, v[order])
+
+
+@pytest.mark.parametrize("m", [100_000, 1_000_000])
+def test_radix_sort_pairs_runs_of_equal_digits(ctx, m):
+    """Keys that are already sorted, and keys from a handful of values: every pass sees long runs of equal digits in neighbouring
+    lanes -- what the histogram sweeps add up run by run (hist_add_runs) instead of lane by lane."""
+    rng = np.random.default_rng(m)
+    for k in (np.sort(rng.integers(0, 2**40, size=m, dtype=np.uint64)),
+              rng.choice(np.array([3, 3 << 8, 0x0102030405, 7 << 32], dtype=np.uint64), size=m),
+              np.repeat(rng.integers(0, 2**40, size=(m + 99) // 100, dtype=np.uint64), 100)[:m]):
+        v = np.arange(m, dtype=np.uint32)
+        ks, vs = ctx.debug_sort_pairs(k, v, 40)
+        order = np.argsort(k, kind="stable")
+        assert np.array_equal(ks, k[order]) and np.array_equal(vs, v[order])
 
 
 def _inputs_small():
